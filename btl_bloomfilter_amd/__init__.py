@@ -1,0 +1,12 @@
+"""MI355X-native k-mer Bloom filter engine -- Python host side.
+
+Thin callers of the C ABI in include/btlbf.h (libbtlbf.so: hand-written HIP for gfx950).  The
+classes mirror the reference's public interface for the hot path (BloomFilter /
+CountingBloomFilter insert / contains / insertAndCheck, ntHashIterator / stHashIterator hash
+streams, BTLBloomFilter_v1 files).  There is no CPU implementation behind them."""
+from . import _lib  # noqa: F401
+from .engine import (BloomFilter, CountingBloomFilter, hash_seqs, sthash_seqs, synth_reads_device,  # noqa: F401
+                     bits_to_bool)
+
+__all__ = ["BloomFilter", "CountingBloomFilter", "hash_seqs", "sthash_seqs", "synth_reads_device",
+           "bits_to_bool"]

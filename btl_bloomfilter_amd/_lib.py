@@ -1,0 +1,101 @@
+"""ctypes binding of the C ABI in include/btlbf.h (libbtlbf.so, hand-written HIP for gfx950).
+
+There is no Python or CPU fallback: if the shared library is missing this module raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbtlbf.so")
+
+HOST, DEVICE = 0, 1
+BLOOM, COUNTING8 = 0, 1
+INCREMENT_MIN, INCREMENT_ALL = 0, 1
+ORDER_PARALLEL, ORDER_SERIAL = 0, 1
+OK, EINVAL, ENOMEM, EIO, EFORMAT, EHIP = range(6)
+
+
+class Layout(C.Structure):
+    _fields_ = [("starts", C.c_void_p), ("n_seqs", C.c_uint64), ("read_len", C.c_uint32)]
+
+
+class BtlbfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("btlbf error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes)
+_P = C.c_void_p
+_PROTOS = {
+    "btlbf_last_error": (C.c_char_p, []),
+    "btlbf_device_count": (C.c_int, []),
+    "btlbf_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_uint64, C.c_uint, C.c_uint, C.c_uint, C.c_int]),
+    "btlbf_create_shard": (C.c_int, [C.POINTER(_P), C.c_int, C.c_uint64, C.c_uint, C.c_uint, C.c_uint,
+                                     C.c_uint, C.c_uint, C.c_int]),
+    "btlbf_destroy": (C.c_int, [_P]),
+    "btlbf_load": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_uint, C.c_int]),
+    "btlbf_store": (C.c_int, [_P, C.c_char_p]),
+    "btlbf_header": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "btlbf_store_shard": (C.c_int, [_P, C.c_char_p]),
+    "btlbf_kind": (C.c_int, [_P]),
+    "btlbf_size": (C.c_uint64, [_P]),
+    "btlbf_size_bytes": (C.c_uint64, [_P]),
+    "btlbf_local_bytes": (C.c_uint64, [_P]),
+    "btlbf_hash_num": (C.c_uint, [_P]),
+    "btlbf_kmer_size": (C.c_uint, [_P]),
+    "btlbf_threshold": (C.c_uint, [_P]),
+    "btlbf_get_n_entry": (C.c_uint64, [_P]),
+    "btlbf_get_t_entry": (C.c_uint64, [_P]),
+    "btlbf_set_n_entry": (None, [_P, C.c_uint64]),
+    "btlbf_set_t_entry": (None, [_P, C.c_uint64]),
+    "btlbf_device_ptr": (_P, [_P]),
+    "btlbf_device": (C.c_int, [_P]),
+    "btlbf_clear": (C.c_int, [_P, _P]),
+    "btlbf_upload": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
+    "btlbf_download": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
+    "btlbf_set_spaced_seeds": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_uint, C.c_uint]),
+    "btlbf_insert_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_int, C.c_int, C.c_int, _P]),
+    "btlbf_contains_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), _P, _P, _P, C.c_int, _P]),
+    "btlbf_insert_and_check_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), _P, _P, _P, C.c_int, _P]),
+    "btlbf_min_count_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), _P, _P, C.c_int, _P]),
+    "btlbf_insert_hashes": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
+    "btlbf_contains_hashes": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, _P]),
+    "btlbf_insert_and_check_hashes": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P]),
+    "btlbf_min_count_hashes": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, _P]),
+    "btlbf_hash_seqs": (C.c_int, [C.c_uint, C.c_uint, C.POINTER(C.c_char_p), C.c_uint, C.c_uint, _P, C.c_uint64,
+                                  C.POINTER(Layout), _P, _P, _P, C.c_int, C.c_int, _P]),
+    "btlbf_popcount": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "btlbf_filtered_popcount": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "btlbf_positions_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_uint, _P, _P, C.c_uint64, _P, _P]),
+    "btlbf_insert_positions": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "btlbf_test_positions": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
+    "btlbf_and_answers": (C.c_int, [_P, _P, C.c_uint64, C.c_uint, _P, C.c_int, _P]),
+    "btlbf_synth_reads": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_int, _P]),
+    "btlbf_microbench": (C.c_int, [_P, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+}
+EXPORTS = sorted(_PROTOS)
+
+
+def load(path=LIB_PATH):
+    """Load libbtlbf.so (no GPU needed to load).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build it with `python -m btl_bloomfilter_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        raise BtlbfError(rc, load().btlbf_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,357 @@
+// csrc/aux_kernels.hip -- everything around the fused sequence kernel:
+//   * probes from precomputed hash rows (BloomFilter::insert/contains/insertAndCheck(const uint64_t[]),
+//     BloomFilter.hpp:185-262; CountingBloomFilter minCount/insert/incrementAll, :53-64,135-183),
+//     in parallel or in strict serial order (one lane) for order-dependent operations
+//   * popcount reductions (getPop BloomFilter.hpp:316-323; popCount/filtered_popcount
+//     CountingBloomFilter.hpp:217-242)
+//   * synthetic read generator and the random-access microbenchmarks
+//   * shard-local position insert/test and the origin-side AND of routed answers
+#include "device_utils.hpp"
+
+namespace btlbf {
+
+
+template <bool POW2>
+__device__ __forceinline__ void hash_row_op(int op, void* filter, const ModParams& mod, uint32_t h,
+                                            uint32_t threshold, const uint64_t* row, uint8_t* out)
+{
+	uint32_t* words = static_cast<uint32_t*>(filter);
+	switch (op) {
+	case H_BF_INSERT:
+		for (uint32_t i = 0; i < h; ++i) {
+			const uint64_t p = reduce_mod<POW2>(row[i], mod) - mod.shard_lo;
+			if (p < mod.shard_len)
+				bf_set(words, p);
+		}
+		break;
+	case H_BF_CONTAINS: {
+		uint32_t all = 1;
+		for (uint32_t i = 0; i < h; ++i) {
+			const uint64_t p = reduce_mod<POW2>(row[i], mod);
+			all &= (bf_word(words, p) >> (p & 31)) & 1u;
+		}
+		*out = (uint8_t)all;
+		break;
+	}
+	case H_BF_INSERT_CHECK: {
+		uint32_t all = 1;
+		for (uint32_t i = 0; i < h; ++i)
+			all &= bf_set_fetch(words, reduce_mod<POW2>(row[i], mod));
+		*out = (uint8_t)all;
+		break;
+	}
+	case H_CBF_INC_ALL:
+		for (uint32_t i = 0; i < h; ++i)
+			cbf_inc_sat(words, reduce_mod<POW2>(row[i], mod));
+		break;
+	case H_CBF_MIN:
+	case H_CBF_CONTAINS:
+	case H_CBF_INSERT_CHECK:
+	case H_CBF_INC_MIN: {
+		if (op != H_CBF_INC_MIN) {
+			uint32_t mn = 0xffu;
+			for (uint32_t i = 0; i < h; ++i) {
+				const uint32_t v = cbf_read_fresh(words, reduce_mod<POW2>(row[i], mod));
+				mn = v < mn ? v : mn;
+			}
+			*out = op == H_CBF_MIN ? (uint8_t)mn : (uint8_t)(mn >= threshold);
+			if (op != H_CBF_INSERT_CHECK)
+				break;
+		}
+		// incrementMin, CountingBloomFilter.hpp:135-162
+		for (;;) {
+			uint32_t mn = 0xffu;
+			for (uint32_t i = 0; i < h; ++i) {
+				const uint32_t v = cbf_read_fresh(words, reduce_mod<POW2>(row[i], mod));
+				mn = v < mn ? v : mn;
+			}
+			if (mn == 0xffu)
+				break;
+			bool done = false;
+			for (uint32_t i = 0; i < h; ++i)
+				done |= cbf_cas_byte(words, reduce_mod<POW2>(row[i], mod), mn);
+			if (done)
+				break;
+		}
+		break;
+	}
+	default: break;
+	}
+}
+
+// one lane per hash row
+template <bool POW2>
+__global__ __launch_bounds__(256) void hash_rows_kernel(int op, void* filter, ModParams mod, uint32_t h,
+                                                        uint32_t threshold, const uint64_t* hashes,
+                                                        uint64_t n, uint8_t* out)
+{
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n;
+	     r += (uint64_t)gridDim.x * blockDim.x) {
+		uint8_t o = 0;
+		hash_row_op<POW2>(op, filter, mod, h, threshold, hashes + r * h, &o);
+		if (out)
+			out[r] = o;
+	}
+}
+
+// strict row order on one lane: the only reproducible form of the order-dependent operations
+// (incrementMin, insertAndCheck on streams with repeats)
+template <bool POW2>
+__global__ void hash_rows_serial_kernel(int op, void* filter, ModParams mod, uint32_t h,
+                                        uint32_t threshold, const uint64_t* hashes, uint64_t n,
+                                        const uint8_t* valid_bits, uint8_t* out)
+{
+	if (blockIdx.x != 0 || threadIdx.x != 0)
+		return;
+	for (uint64_t r = 0; r < n; ++r) {
+		if (valid_bits && !((valid_bits[r >> 3] >> (r & 7)) & 1))
+			continue;
+		uint8_t o = 0;
+		hash_row_op<POW2>(op, filter, mod, h, threshold, hashes + r * h, &o);
+		if (out)
+			out[r] = o;
+	}
+}
+
+hipError_t launch_hash_op(int op, void* filter, const ModParams& mod, uint32_t h, uint32_t threshold,
+                          const uint64_t* hashes, uint64_t n, uint8_t* out, int serial, hipStream_t s)
+{
+	if (n == 0)
+		return hipSuccess;
+	if (serial) {
+		if (mod.pow2)
+			hipLaunchKernelGGL(hash_rows_serial_kernel<true>, dim3(1), dim3(64), 0, s, op, filter, mod, h,
+			                   threshold, hashes, n, (const uint8_t*)nullptr, out);
+		else
+			hipLaunchKernelGGL(hash_rows_serial_kernel<false>, dim3(1), dim3(64), 0, s, op, filter, mod, h,
+			                   threshold, hashes, n, (const uint8_t*)nullptr, out);
+		return hipGetLastError();
+	}
+	uint64_t blocks = (n + 255) / 256;
+	if (blocks > 2048)
+		blocks = 2048;
+	if (mod.pow2)
+		hipLaunchKernelGGL(hash_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, op, filter, mod,
+		                   h, threshold, hashes, n, out);
+	else
+		hipLaunchKernelGGL(hash_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, op, filter, mod,
+		                   h, threshold, hashes, n, out);
+	return hipGetLastError();
+}
+
+// serial-order update over the dense hash rows of a sequence buffer (row p = window p; rows of
+// unclean windows are skipped through valid_bits).  op is a HashOp.
+hipError_t launch_serial_seq_update(const SeqArgs& a, int op, const uint64_t* hashes,
+                                    const uint8_t* valid_bits, uint8_t* out, hipStream_t s)
+{
+	if (a.len == 0)
+		return hipSuccess;
+	if (a.mod.pow2)
+		hipLaunchKernelGGL(hash_rows_serial_kernel<true>, dim3(1), dim3(64), 0, s, op, a.filter, a.mod,
+		                   a.hp.h, a.threshold, hashes, a.len, valid_bits, out);
+	else
+		hipLaunchKernelGGL(hash_rows_serial_kernel<false>, dim3(1), dim3(64), 0, s, op, a.filter, a.mod,
+		                   a.hp.h, a.threshold, hashes, a.len, valid_bits, out);
+	return hipGetLastError();
+}
+
+// ---- popcount ----------------------------------------------------------------------------------
+// mode 0: set bits; mode 1: non-zero bytes; mode 2: bytes >= threshold.  nbytes is padded to 16 by
+// the allocator (padding is zero), so the kernel reads whole uint4s.
+__global__ __launch_bounds__(256) void popcount_kernel(const uint4* data, uint64_t n_vec, int mode,
+                                                       uint32_t threshold, unsigned long long* out)
+{
+	unsigned long long acc = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec;
+	     i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4 v = data[i];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			if (mode == 0) {
+				acc += __popc(w[q]);
+			} else {
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					const uint32_t c = (w[q] >> (8 * b)) & 0xff;
+					acc += mode == 1 ? (c != 0) : (c >= threshold);
+				}
+			}
+		}
+	}
+	// wave reduce, then one atomic per wave
+	for (int o = 32; o > 0; o >>= 1)
+		acc += __shfl_xor(acc, o, 64);
+	if ((threadIdx.x & 63) == 0 && acc)
+		atomicAdd(out, acc);
+}
+
+hipError_t launch_popcount(const void* data, uint64_t nbytes, int mode, uint32_t threshold,
+                           unsigned long long* out, hipStream_t s)
+{
+	const uint64_t n_vec = (nbytes + 15) / 16;
+	if (n_vec == 0)
+		return hipSuccess;
+	uint64_t blocks = (n_vec + 255) / 256;
+	if (blocks > 4096)
+		blocks = 4096;
+	hipLaunchKernelGGL(popcount_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+	                   static_cast<const uint4*>(data), n_vec, mode, threshold, out);
+	return hipGetLastError();
+}
+
+// ---- synthetic reads --------------------------------------------------------------
+// read r, base j = "ACGT"[(w(r*wpr + j/32) >> 2*(j%32)) & 3], w(n) = mix64(seed + (n+1)*golden)
+__global__ __launch_bounds__(256) void synth_kernel(uint8_t* out, uint64_t seed, uint64_t first,
+                                                    uint64_t total_bytes, uint32_t read_len)
+{
+	const uint32_t wpr = (read_len + 31) / 32;
+	for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c * 16 < total_bytes;
+	     c += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t o = c * 16;
+		uint64_t r = o / read_len;
+		uint32_t j = (uint32_t)(o - r * read_len);
+		uint64_t cur_n = ~0ull, w = 0;
+		uint32_t ow[4] = {0, 0, 0, 0};
+		for (int b = 0; b < 16; ++b) {
+			if (o + b >= total_bytes)
+				break;
+			const uint64_t n = (first + r) * wpr + (j >> 5);
+			if (n != cur_n) {
+				cur_n = n;
+				w = mix64(seed + (n + 1) * 0x9E3779B97F4A7C15ULL);
+			}
+			const uint32_t code = (uint32_t)(w >> (2 * (j & 31))) & 3;
+			const uint32_t ch = (0x54474341u >> (8 * code)) & 0xff; // "ACGT"
+			ow[b >> 2] |= ch << (8 * (b & 3));
+			if (++j == read_len) {
+				j = 0;
+				++r;
+			}
+		}
+		if (o + 16 <= total_bytes) {
+			*reinterpret_cast<uint4*>(out + o) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+		} else {
+			for (int b = 0; o + b < total_bytes; ++b)
+				out[o + b] = (uint8_t)(ow[b >> 2] >> (8 * (b & 3)));
+		}
+	}
+}
+
+hipError_t launch_synth(uint8_t* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t read_len,
+                        hipStream_t s)
+{
+	const uint64_t total = n * read_len;
+	if (total == 0)
+		return hipSuccess;
+	uint64_t blocks = ((total + 15) / 16 + 255) / 256;
+	if (blocks > 8192)
+		blocks = 8192;
+	hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, seed, first, total,
+	                   read_len);
+	return hipGetLastError();
+}
+
+// ---- random-access microbenchmarks ---------------------------------------------------------------
+// kind 0: 4-byte loads, kind 1: 4-byte atomicOr; uniformly random 64-byte-aligned offsets; 8
+// independent accesses per lane per round so the memory system, not latency, is the limit.
+__global__ __launch_bounds__(256) void microbench_kernel(uint32_t* data, uint64_t n_lines, int kind,
+                                                         uint64_t rounds, unsigned long long* sink)
+{
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+	uint32_t acc = 0;
+	for (uint64_t it = 0; it < rounds; ++it) {
+		uint64_t idx[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const uint64_t x = mix64((it * 8 + u) * nthreads + gid + 0x1234567ull);
+			idx[u] = (__umul64hi(x, n_lines)) * 16; // uint32 index of a 64-byte line start
+		}
+		if (kind == 0) {
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				acc ^= data[idx[u]];
+		} else {
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				atomicOr(data + idx[u], 1u << (idx[u] >> 4 & 31));
+		}
+	}
+	if (kind == 0 && acc == 0x9e3779b9u)
+		atomicAdd(sink, 1ull); // keeps the loads alive
+}
+
+hipError_t launch_microbench(void* data, uint64_t nbytes, int kind, uint64_t n_access,
+                             unsigned long long* sink, hipStream_t s)
+{
+	const uint64_t n_lines = nbytes / 64;
+	if (n_lines == 0)
+		return hipErrorInvalidValue;
+	const unsigned blocks = 256 * 8;
+	const uint64_t nthreads = (uint64_t)blocks * 256;
+	uint64_t rounds = n_access / (nthreads * 8);
+	if (rounds == 0)
+		rounds = 1;
+	hipLaunchKernelGGL(microbench_kernel, dim3(blocks), dim3(256), 0, s, static_cast<uint32_t*>(data),
+	                   n_lines, kind, rounds, sink);
+	return hipGetLastError();
+}
+
+// ---- shard-local positions (multi-GPU) -------------------------------------------------------------
+__global__ __launch_bounds__(256) void positions_kernel(int test, uint32_t* words, int counting,
+                                                        const uint64_t* pos, uint64_t n, uint8_t* out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+	     i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t p = pos[i];
+		if (!test)
+			bf_set(words, p);
+		else
+			out[i] = (uint8_t)((bf_word(words, p) >> (p & 31)) & 1u);
+	}
+	(void)counting;
+}
+
+hipError_t launch_positions(int test, void* filter, const ModParams& mod, const uint64_t* pos,
+                            uint64_t n, uint8_t* out, hipStream_t s)
+{
+	(void)mod;
+	if (n == 0)
+		return hipSuccess;
+	uint64_t blocks = (n + 255) / 256;
+	if (blocks > 2048)
+		blocks = 2048;
+	hipLaunchKernelGGL(positions_kernel, dim3((unsigned)blocks), dim3(256), 0, s, test,
+	                   static_cast<uint32_t*>(filter), 0, pos, n, out);
+	return hipGetLastError();
+}
+
+// origin side of a sharded query: a probe that missed clears its window's bit
+__global__ __launch_bounds__(256) void and_answers_kernel(const uint64_t* tags, const uint8_t* answers,
+                                                          uint64_t n, uint32_t h, uint64_t* hit_bits)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+	     i += (uint64_t)gridDim.x * blockDim.x) {
+		if (!answers[i]) {
+			const uint64_t p = tags[i] / h;
+			atomicAnd(reinterpret_cast<unsigned long long*>(hit_bits) + (p >> 6),
+			          ~(1ull << (p & 63)));
+		}
+	}
+}
+
+hipError_t launch_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, uint32_t h,
+                              uint64_t* hit_bits, hipStream_t s)
+{
+	if (n == 0)
+		return hipSuccess;
+	uint64_t blocks = (n + 255) / 256;
+	if (blocks > 2048)
+		blocks = 2048;
+	hipLaunchKernelGGL(and_answers_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tags, answers, n, h,
+	                   hit_bits);
+	return hipGetLastError();
+}
+
+} // namespace btlbf

@@ -1,0 +1,1176 @@
+// csrc/capi.cpp -- the C ABI declared in include/btlbf.h (host side; compiled by hipcc).
+//
+// Owns the HBM-resident filter arrays, builds the hash/modulo parameter blocks, stages host
+// buffers, launches the HIP kernels and reads/writes BTLBloomFilter_v1 files byte-for-byte the
+// way the reference does (BloomFilter.hpp:107-166,264-314; CountingBloomFilter.hpp:268-368).
+// There is deliberately no CPU implementation of any compute entry point in this file.
+#include "../../include/btlbf.h"
+#include "internal.hpp"
+
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <vector>
+
+using namespace btlbf;
+
+// -------------------------------------------------------------------------------------------------
+// errors
+// -------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+	do {                                                                                           \
+		hipError_t e__ = (expr);                                                                   \
+		if (e__ != hipSuccess)                                                                     \
+			return fail(BTLBF_EHIP, "%s failed: %s", #expr, hipGetErrorString(e__));               \
+	} while (0)
+
+extern "C" const char* btlbf_last_error(void) { return g_err; }
+
+extern "C" int btlbf_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+// -------------------------------------------------------------------------------------------------
+// filter object
+// -------------------------------------------------------------------------------------------------
+struct btlbf_filter {
+	int kind = BTLBF_BLOOM;
+	int device = 0;
+	uint64_t size = 0;        // global bits / counters
+	uint64_t size_bytes = 0;  // global bytes
+	uint64_t local_bytes = 0; // bytes held here
+	uint64_t alloc_bytes = 0; // local_bytes rounded up to 16 (zero padded)
+	unsigned h = 0, k = 0, thr = 0;
+	double dfpr = 0.0;
+	uint64_t n_entry = 0, t_entry = 0;
+	unsigned bits_per_counter = 8;
+	unsigned shard_index = 0, shard_count = 1;
+	void* d_data = nullptr;
+	ModParams mod{};
+	HashParams hp{};
+	// spaced seeds
+	uint64_t* d_pos_tab = nullptr;
+	uint16_t* d_dc_idx = nullptr;
+	// small device scratch for counters
+	unsigned long long* d_scalar = nullptr; // 4 x u64
+};
+
+namespace {
+
+struct DeviceGuard {
+	int prev = -1;
+	bool ok = true;
+	explicit DeviceGuard(int dev)
+	{
+		if (hipGetDevice(&prev) != hipSuccess) {
+			ok = false;
+			return;
+		}
+		if (prev != dev && hipSetDevice(dev) != hipSuccess)
+			ok = false;
+	}
+	~DeviceGuard()
+	{
+		if (prev >= 0)
+			(void)hipSetDevice(prev);
+	}
+};
+
+struct DevBuf {
+	void* p = nullptr;
+	~DevBuf()
+	{
+		if (p)
+			(void)hipFree(p);
+	}
+	hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+	template <class T>
+	T* as()
+	{
+		return static_cast<T*>(p);
+	}
+};
+
+uint64_t srol_n(uint64_t x, unsigned s)
+{
+	uint64_t lo = x & 0x1FFFFFFFFULL, hi = x >> 33;
+	const unsigned a = s % 33, b = s % 31;
+	if (a)
+		lo = ((lo << a) | (lo >> (33 - a))) & 0x1FFFFFFFFULL;
+	if (b)
+		hi = ((hi << b) | (hi >> (31 - b))) & 0x7FFFFFFFULL;
+	return (hi << 33) | lo;
+}
+
+const uint64_t kSeeds[4] = {kSeedA, kSeedC, kSeedG, kSeedT};
+
+void fill_hash_params(HashParams& hp, unsigned k, unsigned h)
+{
+	memset(&hp, 0, sizeof hp);
+	hp.k = k;
+	hp.h = h;
+	hp.kms = (uint64_t)k * kMultiSeed;
+	for (int c = 0; c < 4; ++c) {
+		const uint64_t s = kSeeds[c], rc = kSeeds[c ^ 3];
+		hp.init_tab[c][0] = s;
+		hp.init_tab[c][1] = srol_n(rc, k - 1);
+		hp.in_tab[c][0] = s;
+		hp.in_tab[c][1] = srol_n(rc, k);
+		hp.out_tab[c][0] = srol_n(s, k);
+		hp.out_tab[c][1] = rc;
+	}
+}
+
+// spaced-seed tables on the device; on success the caller owns *d_pos / *d_dc
+int build_spaced(HashParams& hp, const char* const* seeds, unsigned n_seeds, unsigned h2,
+                 uint64_t** d_pos, uint16_t** d_dc)
+{
+	const unsigned k = hp.k;
+	if (n_seeds == 0 || n_seeds > (unsigned)kMaxSeeds || h2 == 0)
+		return fail(BTLBF_EINVAL, "spaced seeds: need 1..%d seeds and h2 >= 1", kMaxSeeds);
+	if ((uint64_t)n_seeds * h2 > (uint64_t)kMaxHash)
+		return fail(BTLBF_EINVAL, "spaced seeds: n_seeds*h2 = %u exceeds %d", n_seeds * h2, kMaxHash);
+	if (k > 1024)
+		return fail(BTLBF_EINVAL, "spaced seeds: k = %u > 1024 unsupported", k);
+	std::vector<uint16_t> dc;
+	for (unsigned j = 0; j < n_seeds; ++j) {
+		if (!seeds[j] || strlen(seeds[j]) != k)
+			return fail(BTLBF_EINVAL, "spaced seed %u must have exactly k = %u characters", j, k);
+		hp.dc_off[j] = (uint32_t)dc.size();
+		for (unsigned i = 0; i < k; ++i)
+			if (seeds[j][i] != '1') // parseSeed keeps the indices of non-'1' (stHashIterator.hpp:27-29)
+				dc.push_back((uint16_t)i);
+	}
+	hp.dc_off[n_seeds] = (uint32_t)dc.size();
+	std::vector<uint64_t> pos((size_t)k * 8);
+	for (unsigned i = 0; i < k; ++i)
+		for (int c = 0; c < 4; ++c) {
+			pos[((size_t)i * 4 + c) * 2 + 0] = srol_n(kSeeds[c], k - 1 - i);
+			pos[((size_t)i * 4 + c) * 2 + 1] = srol_n(kSeeds[c ^ 3], i);
+		}
+	HIP_TRY(hipMalloc((void**)d_pos, pos.size() * 8));
+	HIP_TRY(hipMemcpy(*d_pos, pos.data(), pos.size() * 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)d_dc, dc.size() * 2 + 16));
+	if (!dc.empty())
+		HIP_TRY(hipMemcpy(*d_dc, dc.data(), dc.size() * 2, hipMemcpyHostToDevice));
+	hp.n_seeds = n_seeds;
+	hp.h2 = h2;
+	hp.h = n_seeds * h2;
+	hp.pos_tab = *d_pos;
+	hp.dc_idx = *d_dc;
+	return BTLBF_OK;
+}
+
+void fill_mod(ModParams& m, uint64_t size, uint64_t lo, uint64_t len)
+{
+	memset(&m, 0, sizeof m);
+	m.size = size;
+	m.pow2 = (size & (size - 1)) == 0;
+	m.mask = size - 1;
+	// floor(2^64 / size) for size >= 2 that is not a power of two == floor((2^64-1)/size)
+	m.magic = m.pow2 ? 0 : (~0ULL) / size;
+	m.shard_lo = lo;
+	m.shard_len = len;
+	m.shard_shift = 0xffffffffu;
+	if (len && (len & (len - 1)) == 0) {
+		unsigned s = 0;
+		while ((1ULL << s) < len)
+			++s;
+		m.shard_shift = s;
+	}
+}
+
+uint64_t cbf_round_bytes(uint64_t b) // CountingBloomFilter.hpp:40-49
+{
+	const uint64_t r = b % 8;
+	return r ? b + 8 - r : b;
+}
+
+// ---- header text ---------------------------------------------------------------------------
+std::string toml_double(double v) // cpptoml.h:3477-3494
+{
+	char buf[64];
+	snprintf(buf, sizeof buf, "%#.17g", v);
+	std::string s(buf);
+	size_t p = s.find("e0");
+	if (p != std::string::npos)
+		s.replace(p, 2, "e");
+	p = s.find("e-0");
+	if (p != std::string::npos)
+		s.replace(p, 3, "e-");
+	return s;
+}
+
+// Key order: what libstdc++'s unordered_map yields for the reference's insertion order
+// (cpptoml.h:43-52,3332; BloomFilter.hpp:275-281; CountingBloomFilter.hpp:355-359)
+std::string header_text(const btlbf_filter* f)
+{
+	char buf[640];
+	if (f->kind == BTLBF_BLOOM) {
+		snprintf(buf, sizeof buf,
+		         "[BTLBloomFilter_v1]\n\tnEntry = %llu\n\tdFPR = %s\n\tEntry = %llu\n"
+		         "\tBloomFilterSizeInBytes = %llu\n\tBloomFilterSize = %llu\n\tHashNum = %u\n"
+		         "\tKmerSize = %u\n[HeaderEnd]\n",
+		         (unsigned long long)f->n_entry, toml_double(f->dfpr).c_str(),
+		         (unsigned long long)f->t_entry, (unsigned long long)f->size_bytes,
+		         (unsigned long long)f->size, f->h, f->k);
+	} else {
+		snprintf(buf, sizeof buf,
+		         "[BTLCountingBloomFilter_v1]\n\tBloomFilterSize = %llu\n\tHashNum = %u\n"
+		         "\tKmerSize = %u\n\tBloomFilterSizeInBytes = %llu\n\tBitsPerCounter = %u\n"
+		         "[HeaderEnd]\n",
+		         (unsigned long long)f->size, f->h, f->k, (unsigned long long)f->size_bytes,
+		         f->bits_per_counter);
+	}
+	return buf;
+}
+
+std::string trim(const std::string& s)
+{
+	size_t a = s.find_first_not_of(" \t\r");
+	if (a == std::string::npos)
+		return "";
+	size_t b = s.find_last_not_of(" \t\r");
+	return s.substr(a, b - a + 1);
+}
+
+struct ParsedHeader {
+	bool has[8] = {false};
+	uint64_t size = 0, size_bytes = 0, n_entry = 0, t_entry = 0;
+	unsigned h = 0, k = 0, bits_per_counter = 8;
+	double dfpr = 0;
+	size_t header_len = 0;
+};
+
+// Order-insensitive reader of the "key = value" lines between the magic line and [HeaderEnd]
+// (the reference hands them to a TOML parser, BloomFilter.hpp:118-166).
+int parse_header(FILE* fp, int kind, const char* path, ParsedHeader& out)
+{
+	const char* magic = kind == BTLBF_BLOOM ? "[BTLBloomFilter_v1]" : "[BTLCountingBloomFilter_v1]";
+	std::string line;
+	auto getline = [&](std::string& l) -> bool {
+		l.clear();
+		int c;
+		bool any = false;
+		while ((c = fgetc(fp)) != EOF) {
+			any = true;
+			out.header_len++;
+			if (c == '\n')
+				return true;
+			l.push_back((char)c);
+			if (l.size() > 4096)
+				return true;
+		}
+		return any;
+	};
+	if (!getline(line) || line != magic)
+		return fail(BTLBF_EFORMAT,
+		            "%s: magic string does not match (likely version mismatch): got \"%.60s\", want \"%s\"",
+		            path, line.c_str(), magic);
+	bool end = false;
+	while (getline(line)) {
+		if (line == "[HeaderEnd]") {
+			end = true;
+			break;
+		}
+		const size_t eq = line.find('=');
+		if (eq == std::string::npos)
+			continue;
+		const std::string key = trim(line.substr(0, eq)), val = trim(line.substr(eq + 1));
+		if (key == "BloomFilterSize") {
+			out.size = strtoull(val.c_str(), nullptr, 10);
+			out.has[0] = true;
+		} else if (key == "HashNum") {
+			out.h = (unsigned)strtoul(val.c_str(), nullptr, 10);
+			out.has[1] = true;
+		} else if (key == "KmerSize") {
+			out.k = (unsigned)strtoul(val.c_str(), nullptr, 10);
+			out.has[2] = true;
+		} else if (key == "BloomFilterSizeInBytes") {
+			out.size_bytes = strtoull(val.c_str(), nullptr, 10);
+			out.has[3] = true;
+		} else if (key == "dFPR") {
+			out.dfpr = strtod(val.c_str(), nullptr);
+			out.has[4] = true;
+		} else if (key == "nEntry") {
+			out.n_entry = strtoull(val.c_str(), nullptr, 10);
+			out.has[5] = true;
+		} else if (key == "Entry") {
+			out.t_entry = strtoull(val.c_str(), nullptr, 10);
+			out.has[6] = true;
+		} else if (key == "BitsPerCounter") {
+			out.bits_per_counter = (unsigned)strtoul(val.c_str(), nullptr, 10);
+			out.has[7] = true;
+		}
+	}
+	if (!end)
+		return fail(BTLBF_EFORMAT, "%s: pre-built bloom filter does not have the correct header end", path);
+	const int need_bloom[] = {0, 1, 2, 3, 4, 5, 6}, need_cnt[] = {0, 1, 2, 3, 7};
+	if (kind == BTLBF_BLOOM) {
+		for (int i : need_bloom)
+			if (!out.has[i])
+				return fail(BTLBF_EFORMAT, "%s: header key missing", path);
+	} else {
+		for (int i : need_cnt)
+			if (!out.has[i])
+				return fail(BTLBF_EFORMAT, "%s: header key missing", path);
+	}
+	return BTLBF_OK;
+}
+
+int make_filter(btlbf_filter** out, int kind, uint64_t size, uint64_t size_bytes, unsigned shard_index,
+                unsigned shard_count, unsigned h, unsigned k, unsigned thr, int device)
+{
+	if (!out)
+		return fail(BTLBF_EINVAL, "null out pointer");
+	*out = nullptr;
+	if (kind != BTLBF_BLOOM && kind != BTLBF_COUNTING8)
+		return fail(BTLBF_EINVAL, "unknown filter kind %d", kind);
+	if (h == 0)
+		return fail(BTLBF_EINVAL, "hash_num must be >= 1");
+	if (k == 0 || k > 32768)
+		return fail(BTLBF_EINVAL, "kmer_size must be in 1..32768");
+	if (size < 8)
+		return fail(BTLBF_EINVAL, "filter size %llu too small", (unsigned long long)size);
+	if (shard_count == 0 || shard_index >= shard_count || size % shard_count ||
+	    (size / shard_count) % 64)
+		return fail(BTLBF_EINVAL, "shard %u of %u does not split %llu positions into multiples of 64",
+		            shard_index, shard_count, (unsigned long long)size);
+	if (btlbf_device_count() <= device || device < 0)
+		return fail(BTLBF_EHIP, "no GPU %d (visible devices: %d): this library has no CPU path", device,
+		            btlbf_device_count());
+	DeviceGuard g(device);
+	if (!g.ok)
+		return fail(BTLBF_EHIP, "cannot select GPU %d", device);
+	btlbf_filter* f = new btlbf_filter();
+	f->kind = kind;
+	f->device = device;
+	f->size = size;
+	f->size_bytes = size_bytes;
+	f->h = h;
+	f->k = k;
+	f->thr = thr;
+	f->shard_index = shard_index;
+	f->shard_count = shard_count;
+	const uint64_t len = size / shard_count;
+	f->local_bytes = kind == BTLBF_BLOOM ? len / 8 : len;
+	if (shard_count == 1)
+		f->local_bytes = size_bytes;
+	f->alloc_bytes = (f->local_bytes + 15) / 16 * 16;
+	fill_mod(f->mod, size, (uint64_t)shard_index * len, len);
+	fill_hash_params(f->hp, k, h);
+	hipError_t e = hipMalloc(&f->d_data, f->alloc_bytes);
+	if (e != hipSuccess) {
+		delete f;
+		return fail(e == hipErrorOutOfMemory ? BTLBF_ENOMEM : BTLBF_EHIP, "hipMalloc(%llu bytes): %s",
+		            (unsigned long long)f->alloc_bytes, hipGetErrorString(e));
+	}
+	e = hipMemset(f->d_data, 0, f->alloc_bytes);
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&f->d_scalar, 64);
+	if (e == hipSuccess)
+		e = hipDeviceSynchronize();
+	if (e != hipSuccess) {
+		(void)hipFree(f->d_data);
+		delete f;
+		return fail(BTLBF_EHIP, "filter initialisation: %s", hipGetErrorString(e));
+	}
+	*out = f;
+	return BTLBF_OK;
+}
+
+// device-resident view of a caller's sequence buffer (+ layout), staging host memory if needed
+struct SeqView {
+	DevBuf seq_buf, starts_buf;
+	const uint8_t* d_seq = nullptr;
+	LayoutParams lay{nullptr, 0, 0};
+};
+
+int check_layout(const btlbf_layout* l, uint64_t len)
+{
+	if (!l)
+		return BTLBF_OK;
+	if (l->starts == nullptr && l->read_len && len % l->read_len)
+		return fail(BTLBF_EINVAL, "len %llu is not a multiple of read_len %u", (unsigned long long)len,
+		            l->read_len);
+	return BTLBF_OK;
+}
+
+int make_view(SeqView& v, const char* seq, uint64_t len, const btlbf_layout* l, int mem, hipStream_t s)
+{
+	if (len && !seq)
+		return fail(BTLBF_EINVAL, "null sequence buffer");
+	int rc = check_layout(l, len);
+	if (rc)
+		return rc;
+	if (l) {
+		v.lay.n_seqs = l->n_seqs;
+		v.lay.read_len = l->starts ? 0 : l->read_len;
+	}
+	if (mem == BTLBF_DEVICE) {
+		v.d_seq = reinterpret_cast<const uint8_t*>(seq);
+		if (l && l->starts)
+			v.lay.starts = l->starts;
+		return BTLBF_OK;
+	}
+	if (mem != BTLBF_HOST)
+		return fail(BTLBF_EINVAL, "mem must be BTLBF_HOST or BTLBF_DEVICE");
+	HIP_TRY(v.seq_buf.alloc(len + 16));
+	if (len)
+		HIP_TRY(hipMemcpyAsync(v.seq_buf.p, seq, len, hipMemcpyHostToDevice, s));
+	v.d_seq = v.seq_buf.as<uint8_t>();
+	if (l && l->starts) {
+		if (l->starts[0] != 0 || l->starts[l->n_seqs] != len)
+			return fail(BTLBF_EINVAL, "starts[0] must be 0 and starts[n_seqs] must equal len");
+		HIP_TRY(v.starts_buf.alloc((l->n_seqs + 1) * 8));
+		HIP_TRY(hipMemcpyAsync(v.starts_buf.p, l->starts, (l->n_seqs + 1) * 8, hipMemcpyHostToDevice, s));
+		v.lay.starts = v.starts_buf.as<uint64_t>();
+	}
+	return BTLBF_OK;
+}
+
+SeqArgs base_args(const btlbf_filter* f, const SeqView& v, uint64_t len)
+{
+	SeqArgs a;
+	memset(&a, 0, sizeof a);
+	a.seq = v.d_seq;
+	a.len = len;
+	a.layout = v.lay;
+	a.filter = f->d_data;
+	a.mod = f->mod;
+	a.hp = f->hp;
+	a.threshold = f->thr;
+	return a;
+}
+
+uint64_t bitmap_bytes(uint64_t len) { return (len + 63) / 64 * 8; }
+
+} // namespace
+
+// -------------------------------------------------------------------------------------------------
+// lifetime
+// -------------------------------------------------------------------------------------------------
+extern "C" int btlbf_create(btlbf_filter** out, int kind, uint64_t size, unsigned hash_num,
+                            unsigned kmer_size, unsigned threshold, int device)
+{
+	if (kind == BTLBF_BLOOM) {
+		if (size % 8 != 0) // BloomFilter.hpp:391-394
+			return fail(BTLBF_EINVAL, "ERROR: Filter Size \"%llu\" is not a multiple of 8.",
+			            (unsigned long long)size);
+		return make_filter(out, kind, size, size / 8, 0, 1, hash_num, kmer_size, 0, device);
+	}
+	const uint64_t bytes = cbf_round_bytes(size);
+	return make_filter(out, kind, bytes, bytes, 0, 1, hash_num, kmer_size, threshold, device);
+}
+
+extern "C" int btlbf_create_shard(btlbf_filter** out, int kind, uint64_t global_size,
+                                  unsigned shard_index, unsigned shard_count, unsigned hash_num,
+                                  unsigned kmer_size, unsigned threshold, int device)
+{
+	if (kind == BTLBF_BLOOM) {
+		if (global_size % 8 != 0)
+			return fail(BTLBF_EINVAL, "ERROR: Filter Size \"%llu\" is not a multiple of 8.",
+			            (unsigned long long)global_size);
+		return make_filter(out, kind, global_size, global_size / 8, shard_index, shard_count, hash_num,
+		                   kmer_size, 0, device);
+	}
+	const uint64_t bytes = cbf_round_bytes(global_size);
+	return make_filter(out, kind, bytes, bytes, shard_index, shard_count, hash_num, kmer_size, threshold,
+	                   device);
+}
+
+extern "C" int btlbf_destroy(btlbf_filter* f)
+{
+	if (!f)
+		return BTLBF_OK;
+	DeviceGuard g(f->device);
+	(void)hipFree(f->d_data);
+	(void)hipFree(f->d_scalar);
+	(void)hipFree(f->d_pos_tab);
+	(void)hipFree(f->d_dc_idx);
+	delete f;
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_set_spaced_seeds(btlbf_filter* f, const char* const* seeds, unsigned n_seeds,
+                                      unsigned h2)
+{
+	if (!f || !seeds)
+		return fail(BTLBF_EINVAL, "null argument");
+	if (n_seeds * h2 != f->h)
+		return fail(BTLBF_EINVAL, "n_seeds*h2 = %u must equal the filter's hash_num %u", n_seeds * h2, f->h);
+	DeviceGuard g(f->device);
+	HashParams hp;
+	fill_hash_params(hp, f->k, f->h);
+	uint64_t* dp = nullptr;
+	uint16_t* dd = nullptr;
+	int rc = build_spaced(hp, seeds, n_seeds, h2, &dp, &dd);
+	if (rc) {
+		(void)hipFree(dp);
+		(void)hipFree(dd);
+		return rc;
+	}
+	(void)hipFree(f->d_pos_tab);
+	(void)hipFree(f->d_dc_idx);
+	f->d_pos_tab = dp;
+	f->d_dc_idx = dd;
+	f->hp = hp;
+	return BTLBF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// attributes
+// -------------------------------------------------------------------------------------------------
+extern "C" int btlbf_kind(const btlbf_filter* f) { return f->kind; }
+extern "C" uint64_t btlbf_size(const btlbf_filter* f) { return f->size; }
+extern "C" uint64_t btlbf_size_bytes(const btlbf_filter* f) { return f->size_bytes; }
+extern "C" uint64_t btlbf_local_bytes(const btlbf_filter* f) { return f->local_bytes; }
+extern "C" unsigned btlbf_hash_num(const btlbf_filter* f) { return f->h; }
+extern "C" unsigned btlbf_kmer_size(const btlbf_filter* f) { return f->k; }
+extern "C" unsigned btlbf_threshold(const btlbf_filter* f) { return f->thr; }
+extern "C" uint64_t btlbf_get_n_entry(const btlbf_filter* f) { return f->n_entry; }
+extern "C" uint64_t btlbf_get_t_entry(const btlbf_filter* f) { return f->t_entry; }
+extern "C" void btlbf_set_n_entry(btlbf_filter* f, uint64_t v) { f->n_entry = v; }
+extern "C" void btlbf_set_t_entry(btlbf_filter* f, uint64_t v) { f->t_entry = v; }
+extern "C" void* btlbf_device_ptr(const btlbf_filter* f) { return f->d_data; }
+extern "C" int btlbf_device(const btlbf_filter* f) { return f->device; }
+
+extern "C" int btlbf_clear(btlbf_filter* f, void* stream)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	DeviceGuard g(f->device);
+	HIP_TRY(hipMemsetAsync(f->d_data, 0, f->alloc_bytes, static_cast<hipStream_t>(stream)));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_upload(btlbf_filter* f, const void* src, uint64_t offset, uint64_t nbytes)
+{
+	if (!f || (!src && nbytes))
+		return fail(BTLBF_EINVAL, "null argument");
+	if (offset + nbytes > f->local_bytes)
+		return fail(BTLBF_EINVAL, "upload range exceeds the filter");
+	DeviceGuard g(f->device);
+	HIP_TRY(hipMemcpy(static_cast<uint8_t*>(f->d_data) + offset, src, nbytes, hipMemcpyHostToDevice));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_download(const btlbf_filter* f, void* dst, uint64_t offset, uint64_t nbytes)
+{
+	if (!f || (!dst && nbytes))
+		return fail(BTLBF_EINVAL, "null argument");
+	if (offset + nbytes > f->local_bytes)
+		return fail(BTLBF_EINVAL, "download range exceeds the filter");
+	DeviceGuard g(f->device);
+	HIP_TRY(hipMemcpy(dst, static_cast<const uint8_t*>(f->d_data) + offset, nbytes, hipMemcpyDeviceToHost));
+	return BTLBF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// files
+// -------------------------------------------------------------------------------------------------
+extern "C" int btlbf_header(const btlbf_filter* f, char* buf, size_t cap, size_t* len)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	const std::string h = header_text(f);
+	if (len)
+		*len = h.size();
+	if (buf) {
+		if (cap < h.size())
+			return fail(BTLBF_EINVAL, "header buffer too small (%zu < %zu)", cap, h.size());
+		memcpy(buf, h.data(), h.size());
+	}
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_load(btlbf_filter** out, int kind, const char* path, unsigned threshold, int device)
+{
+	if (!out || !path)
+		return fail(BTLBF_EINVAL, "null argument");
+	*out = nullptr;
+	FILE* fp = fopen(path, "rb");
+	if (!fp)
+		return fail(BTLBF_EIO, "error: `%s': %s", path, strerror(errno));
+	ParsedHeader ph;
+	int rc = parse_header(fp, kind, path, ph);
+	if (rc) {
+		fclose(fp);
+		return rc;
+	}
+	btlbf_filter* f = nullptr;
+	if (kind == BTLBF_BLOOM) {
+		if (ph.size % 8 != 0) {
+			fclose(fp);
+			return fail(BTLBF_EINVAL, "ERROR: Filter Size \"%llu\" is not a multiple of 8.",
+			            (unsigned long long)ph.size);
+		}
+		rc = make_filter(&f, kind, ph.size, ph.size / 8, 0, 1, ph.h, ph.k, 0, device);
+	} else {
+		if (ph.bits_per_counter != 8 || ph.size != ph.size_bytes) {
+			fclose(fp);
+			return fail(BTLBF_EFORMAT, "%s: only 8-bit counters are supported (BitsPerCounter = %u)", path,
+			            ph.bits_per_counter);
+		}
+		rc = make_filter(&f, kind, ph.size, ph.size_bytes, 0, 1, ph.h, ph.k, threshold, device);
+	}
+	if (rc) {
+		fclose(fp);
+		return rc;
+	}
+	f->dfpr = ph.dfpr;
+	f->n_entry = ph.n_entry;
+	f->t_entry = ph.t_entry;
+	// body: stream through a pinned bounce buffer
+	const size_t chunk = 64u << 20;
+	void* bounce = nullptr;
+	DeviceGuard g(device);
+	if (hipHostMalloc(&bounce, chunk, hipHostMallocDefault) != hipSuccess) {
+		fclose(fp);
+		btlbf_destroy(f);
+		return fail(BTLBF_ENOMEM, "pinned bounce buffer");
+	}
+	uint64_t done = 0;
+	while (done < f->local_bytes) {
+		const size_t n = (size_t)std::min<uint64_t>(chunk, f->local_bytes - done);
+		if (fread(bounce, 1, n, fp) != n) {
+			(void)hipHostFree(bounce);
+			fclose(fp);
+			btlbf_destroy(f);
+			return fail(BTLBF_EIO, "error: `%s': short read of the filter body", path);
+		}
+		if (hipMemcpy(static_cast<uint8_t*>(f->d_data) + done, bounce, n, hipMemcpyHostToDevice) != hipSuccess) {
+			(void)hipHostFree(bounce);
+			fclose(fp);
+			btlbf_destroy(f);
+			return fail(BTLBF_EHIP, "upload of the filter body failed");
+		}
+		done += n;
+	}
+	(void)hipHostFree(bounce);
+	fclose(fp);
+	*out = f;
+	return BTLBF_OK;
+}
+
+static int write_body(const btlbf_filter* f, int fd, uint64_t file_off, const char* path)
+{
+	const size_t chunk = 64u << 20;
+	void* bounce = nullptr;
+	if (hipHostMalloc(&bounce, chunk, hipHostMallocDefault) != hipSuccess)
+		return fail(BTLBF_ENOMEM, "pinned bounce buffer");
+	uint64_t done = 0;
+	int rc = BTLBF_OK;
+	while (done < f->local_bytes && rc == BTLBF_OK) {
+		const size_t n = (size_t)std::min<uint64_t>(chunk, f->local_bytes - done);
+		if (hipMemcpy(bounce, static_cast<const uint8_t*>(f->d_data) + done, n, hipMemcpyDeviceToHost) !=
+		    hipSuccess) {
+			rc = fail(BTLBF_EHIP, "download of the filter body failed");
+			break;
+		}
+		size_t w = 0;
+		while (w < n) {
+			ssize_t r = pwrite(fd, static_cast<const char*>(bounce) + w, n - w, (off_t)(file_off + done + w));
+			if (r <= 0) {
+				rc = fail(BTLBF_EIO, "error: `%s': %s", path, strerror(errno));
+				break;
+			}
+			w += (size_t)r;
+		}
+		done += n;
+	}
+	(void)hipHostFree(bounce);
+	return rc;
+}
+
+extern "C" int btlbf_store_shard(btlbf_filter* f, const char* path)
+{
+	if (!f || !path)
+		return fail(BTLBF_EINVAL, "null argument");
+	DeviceGuard g(f->device);
+	HIP_TRY(hipDeviceSynchronize());
+	const std::string hdr = header_text(f);
+	const int flags = O_WRONLY | O_CREAT | (f->shard_count == 1 ? O_TRUNC : 0);
+	const int fd = open(path, flags, 0644);
+	if (fd < 0)
+		return fail(BTLBF_EIO, "error: `%s': %s", path, strerror(errno));
+	int rc = BTLBF_OK;
+	if (f->shard_index == 0) {
+		if (pwrite(fd, hdr.data(), hdr.size(), 0) != (ssize_t)hdr.size())
+			rc = fail(BTLBF_EIO, "error: `%s': %s", path, strerror(errno));
+		if (rc == BTLBF_OK && f->shard_count > 1 && ftruncate(fd, (off_t)(hdr.size() + f->size_bytes)) != 0)
+			rc = fail(BTLBF_EIO, "error: `%s': %s", path, strerror(errno));
+	}
+	if (rc == BTLBF_OK)
+		rc = write_body(f, fd, hdr.size() + (uint64_t)f->shard_index * f->local_bytes, path);
+	if (close(fd) != 0 && rc == BTLBF_OK)
+		rc = fail(BTLBF_EIO, "error: `%s': %s", path, strerror(errno));
+	return rc;
+}
+
+extern "C" int btlbf_store(btlbf_filter* f, const char* path)
+{
+	if (f && f->shard_count != 1)
+		return fail(BTLBF_EINVAL, "btlbf_store on a shard: use btlbf_store_shard");
+	return btlbf_store_shard(f, path);
+}
+
+// -------------------------------------------------------------------------------------------------
+// the hot path
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+int seq_precheck(const btlbf_filter* f, uint64_t len)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	if (f->hp.n_seeds == 0 && f->h > 64)
+		return fail(BTLBF_EINVAL, "hash_num %u > 64 unsupported by the sequence kernels", f->h);
+	(void)len;
+	return BTLBF_OK;
+}
+
+// copy a device bitmap / array back to the caller when the call was BTLBF_HOST
+struct OutBuf {
+	DevBuf dev;
+	void* host = nullptr;
+	size_t n = 0;
+	void* d = nullptr;
+	int prepare(void* user, size_t nbytes, int mem, bool zero, hipStream_t s)
+	{
+		n = nbytes;
+		if (!user)
+			return BTLBF_OK;
+		if (mem == BTLBF_DEVICE) {
+			d = user;
+		} else {
+			host = user;
+			HIP_TRY(dev.alloc(nbytes));
+			d = dev.p;
+		}
+		if (zero && nbytes)
+			HIP_TRY(hipMemsetAsync(d, 0, nbytes, s));
+		return BTLBF_OK;
+	}
+	int finish(hipStream_t s)
+	{
+		if (host && n)
+			HIP_TRY(hipMemcpyAsync(host, d, n, hipMemcpyDeviceToHost, s));
+		return BTLBF_OK;
+	}
+};
+
+int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const btlbf_layout* layout,
+                   uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts, uint8_t* min_out, int mem,
+                   void* stream)
+{
+	int rc = seq_precheck(f, len);
+	if (rc)
+		return rc;
+	if (f->shard_count != 1)
+		return fail(BTLBF_EINVAL, "queries on a shard go through btlbf_positions_seqs/btlbf_test_positions");
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	SeqView v;
+	rc = make_view(v, seq, len, layout, mem, s);
+	if (rc)
+		return rc;
+	OutBuf ob_hit, ob_valid, ob_cnt, ob_min;
+	if ((rc = ob_hit.prepare(hit_bits, bitmap_bytes(len), mem, false, s)))
+		return rc;
+	if ((rc = ob_valid.prepare(valid_bits, bitmap_bytes(len), mem, false, s)))
+		return rc;
+	if ((rc = ob_cnt.prepare(counts, 16, mem, true, s)))
+		return rc;
+	if ((rc = ob_min.prepare(min_out, len, mem, false, s)))
+		return rc;
+	SeqArgs a = base_args(f, v, len);
+	a.hit_bits = static_cast<uint8_t*>(ob_hit.d);
+	a.valid_bits = static_cast<uint8_t*>(ob_valid.d);
+	a.counts = static_cast<uint64_t*>(ob_cnt.d);
+	a.min_out = static_cast<uint8_t*>(ob_min.d);
+	HIP_TRY(launch_seq_op(op, a, s));
+	if ((rc = ob_hit.finish(s)) || (rc = ob_valid.finish(s)) || (rc = ob_cnt.finish(s)) ||
+	    (rc = ob_min.finish(s)))
+		return rc;
+	if (mem == BTLBF_HOST)
+		HIP_TRY(hipStreamSynchronize(s));
+	return BTLBF_OK;
+}
+
+} // namespace
+
+extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
+                                 const btlbf_layout* layout, int op, int order, int mem, void* stream)
+{
+	int rc = seq_precheck(f, len);
+	if (rc)
+		return rc;
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	SeqView v;
+	rc = make_view(v, seq, len, layout, mem, s);
+	if (rc)
+		return rc;
+	SeqArgs a = base_args(f, v, len);
+	int kop;
+	if (f->kind == BTLBF_BLOOM) {
+		kop = OP_BF_INSERT; // bit OR is order-free: serial order would give the same bytes
+	} else {
+		if (f->shard_count != 1)
+			return fail(BTLBF_EINVAL, "counting filters are not sharded in this version");
+		if (op != BTLBF_INCREMENT_MIN && op != BTLBF_INCREMENT_ALL)
+			return fail(BTLBF_EINVAL, "op must be BTLBF_INCREMENT_MIN or BTLBF_INCREMENT_ALL");
+		kop = op == BTLBF_INCREMENT_MIN ? OP_CBF_INC_MIN : OP_CBF_INC_ALL;
+		if (order == BTLBF_ORDER_SERIAL) {
+			// hash on all CUs, then apply the rows in buffer order on a single lane
+			DevBuf hashes, valid;
+			HIP_TRY(hashes.alloc(len * f->h * 8));
+			HIP_TRY(valid.alloc(bitmap_bytes(len)));
+			a.hashes = hashes.as<uint64_t>();
+			a.valid_bits = valid.as<uint8_t>();
+			HIP_TRY(launch_seq_op(OP_HASH_ONLY, a, s));
+			HIP_TRY(launch_serial_seq_update(a, op == BTLBF_INCREMENT_MIN ? H_CBF_INC_MIN : H_CBF_INC_ALL,
+			                                 hashes.as<uint64_t>(), valid.as<uint8_t>(), nullptr, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			return BTLBF_OK;
+		}
+	}
+	HIP_TRY(launch_seq_op(kop, a, s));
+	if (mem == BTLBF_HOST)
+		HIP_TRY(hipStreamSynchronize(s));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_contains_seqs(btlbf_filter* f, const char* seq, uint64_t len,
+                                   const btlbf_layout* layout, uint64_t* hit_bits, uint64_t* valid_bits,
+                                   uint64_t* counts, int mem, void* stream)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	return run_query_like(f, f->kind == BTLBF_BLOOM ? OP_BF_CONTAINS : OP_CBF_QUERY, seq, len, layout,
+	                      hit_bits, valid_bits, counts, nullptr, mem, stream);
+}
+
+extern "C" int btlbf_insert_and_check_seqs(btlbf_filter* f, const char* seq, uint64_t len,
+                                           const btlbf_layout* layout, uint64_t* hit_bits,
+                                           uint64_t* valid_bits, uint64_t* counts, int mem, void* stream)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	if (f->kind != BTLBF_BLOOM)
+		return fail(BTLBF_EINVAL, "insert_and_check_seqs: bit filters only (use the hash-row form for counting)");
+	return run_query_like(f, OP_BF_INSERT_CHECK, seq, len, layout, hit_bits, valid_bits, counts, nullptr, mem,
+	                      stream);
+}
+
+extern "C" int btlbf_min_count_seqs(btlbf_filter* f, const char* seq, uint64_t len,
+                                    const btlbf_layout* layout, uint8_t* min_out, uint64_t* valid_bits,
+                                    int mem, void* stream)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	if (f->kind != BTLBF_COUNTING8)
+		return fail(BTLBF_EINVAL, "min_count needs a counting filter");
+	return run_query_like(f, OP_CBF_QUERY, seq, len, layout, nullptr, valid_bits, nullptr, min_out, mem, stream);
+}
+
+// -------------------------------------------------------------------------------------------------
+// precomputed hash rows
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+int run_hash_rows(btlbf_filter* f, int hop, const uint64_t* hashes, uint64_t n, uint8_t* out, int serial,
+                  int mem, void* stream)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	if (n && !hashes)
+		return fail(BTLBF_EINVAL, "null hashes");
+	if (f->shard_count != 1 && hop != H_BF_INSERT)
+		return fail(BTLBF_EINVAL, "only insert is defined on a single shard");
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	DevBuf hb;
+	const uint64_t* d_h = hashes;
+	if (mem == BTLBF_HOST) {
+		HIP_TRY(hb.alloc(n * f->h * 8));
+		if (n)
+			HIP_TRY(hipMemcpyAsync(hb.p, hashes, n * f->h * 8, hipMemcpyHostToDevice, s));
+		d_h = hb.as<uint64_t>();
+	}
+	OutBuf ob;
+	int rc = ob.prepare(out, n, mem, false, s);
+	if (rc)
+		return rc;
+	HIP_TRY(launch_hash_op(hop, f->d_data, f->mod, f->h, f->thr, d_h, n, static_cast<uint8_t*>(ob.d), serial, s));
+	if ((rc = ob.finish(s)))
+		return rc;
+	if (mem == BTLBF_HOST)
+		HIP_TRY(hipStreamSynchronize(s));
+	return BTLBF_OK;
+}
+
+} // namespace
+
+extern "C" int btlbf_insert_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, int op, int order,
+                                   int mem, void* stream)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	int hop = H_BF_INSERT;
+	if (f->kind == BTLBF_COUNTING8) {
+		if (op != BTLBF_INCREMENT_MIN && op != BTLBF_INCREMENT_ALL)
+			return fail(BTLBF_EINVAL, "op must be BTLBF_INCREMENT_MIN or BTLBF_INCREMENT_ALL");
+		hop = op == BTLBF_INCREMENT_MIN ? H_CBF_INC_MIN : H_CBF_INC_ALL;
+	}
+	const int serial = f->kind == BTLBF_COUNTING8 && order == BTLBF_ORDER_SERIAL;
+	return run_hash_rows(f, hop, hashes, n, nullptr, serial, mem, stream);
+}
+
+extern "C" int btlbf_contains_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, uint8_t* out,
+                                     int mem, void* stream)
+{
+	if (!f || !out)
+		return fail(BTLBF_EINVAL, "null argument");
+	return run_hash_rows(f, f->kind == BTLBF_BLOOM ? H_BF_CONTAINS : H_CBF_CONTAINS, hashes, n, out, 0, mem,
+	                     stream);
+}
+
+extern "C" int btlbf_insert_and_check_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n,
+                                             uint8_t* out, int order, int mem, void* stream)
+{
+	if (!f || !out)
+		return fail(BTLBF_EINVAL, "null argument");
+	return run_hash_rows(f, f->kind == BTLBF_BLOOM ? H_BF_INSERT_CHECK : H_CBF_INSERT_CHECK, hashes, n, out,
+	                     order == BTLBF_ORDER_SERIAL, mem, stream);
+}
+
+extern "C" int btlbf_min_count_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, uint8_t* min_out,
+                                      int mem, void* stream)
+{
+	if (!f || !min_out)
+		return fail(BTLBF_EINVAL, "null argument");
+	if (f->kind != BTLBF_COUNTING8)
+		return fail(BTLBF_EINVAL, "min_count needs a counting filter");
+	return run_hash_rows(f, H_CBF_MIN, hashes, n, min_out, 0, mem, stream);
+}
+
+// -------------------------------------------------------------------------------------------------
+// hash streams only
+// -------------------------------------------------------------------------------------------------
+extern "C" int btlbf_hash_seqs(unsigned kmer_size, unsigned hash_num, const char* const* seeds,
+                               unsigned n_seeds, unsigned h2, const char* seq, uint64_t len,
+                               const btlbf_layout* layout, uint64_t* hashes, uint64_t* valid_bits,
+                               uint64_t* strand_bits, int mem, int device, void* stream)
+{
+	if (kmer_size == 0 || kmer_size > 32768 || hash_num == 0)
+		return fail(BTLBF_EINVAL, "bad kmer_size / hash_num");
+	if (!seeds && hash_num > 64)
+		return fail(BTLBF_EINVAL, "hash_num %u > 64 unsupported", hash_num);
+	if (btlbf_device_count() <= device || device < 0)
+		return fail(BTLBF_EHIP, "no GPU %d (visible devices: %d): this library has no CPU path", device,
+		            btlbf_device_count());
+	DeviceGuard g(device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	HashParams hp;
+	fill_hash_params(hp, kmer_size, hash_num);
+	DevBuf pos_owner, dc_owner;
+	if (seeds) {
+		if (n_seeds * h2 != hash_num)
+			return fail(BTLBF_EINVAL, "hash_num must equal n_seeds*h2");
+		uint64_t* dp = nullptr;
+		uint16_t* dd = nullptr;
+		int rc = build_spaced(hp, seeds, n_seeds, h2, &dp, &dd);
+		pos_owner.p = dp;
+		dc_owner.p = dd;
+		if (rc)
+			return rc;
+	}
+	SeqView v;
+	int rc = make_view(v, seq, len, layout, mem, s);
+	if (rc)
+		return rc;
+	OutBuf ob_h, ob_v, ob_s;
+	if ((rc = ob_h.prepare(hashes, len * hash_num * 8, mem, false, s)))
+		return rc;
+	if ((rc = ob_v.prepare(valid_bits, bitmap_bytes(len), mem, false, s)))
+		return rc;
+	if ((rc = ob_s.prepare(strand_bits, len * 8, mem, false, s)))
+		return rc;
+	SeqArgs a;
+	memset(&a, 0, sizeof a);
+	a.seq = v.d_seq;
+	a.len = len;
+	a.layout = v.lay;
+	a.hp = hp;
+	fill_mod(a.mod, 8, 0, 8);
+	a.hashes = static_cast<uint64_t*>(ob_h.d);
+	a.valid_bits = static_cast<uint8_t*>(ob_v.d);
+	a.strand_bits = static_cast<uint64_t*>(ob_s.d);
+	if (!a.hashes)
+		return fail(BTLBF_EINVAL, "null hashes output");
+	HIP_TRY(launch_seq_op(OP_HASH_ONLY, a, s));
+	if ((rc = ob_h.finish(s)) || (rc = ob_v.finish(s)) || (rc = ob_s.finish(s)))
+		return rc;
+	HIP_TRY(hipStreamSynchronize(s)); // tables are freed on return
+	return BTLBF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// statistics
+// -------------------------------------------------------------------------------------------------
+static int popcount_mode(btlbf_filter* f, int mode, uint64_t* out)
+{
+	if (!f || !out)
+		return fail(BTLBF_EINVAL, "null argument");
+	DeviceGuard g(f->device);
+	HIP_TRY(hipMemset(f->d_scalar, 0, 8));
+	HIP_TRY(launch_popcount(f->d_data, f->alloc_bytes, mode, f->thr, f->d_scalar, nullptr));
+	unsigned long long v = 0;
+	HIP_TRY(hipMemcpy(&v, f->d_scalar, 8, hipMemcpyDeviceToHost));
+	if (mode == 2 && f->thr == 0)
+		v -= f->alloc_bytes - f->local_bytes; // zero padding also passes ">= 0"
+	*out = v;
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_popcount(btlbf_filter* f, uint64_t* out)
+{
+	return popcount_mode(f, f && f->kind == BTLBF_COUNTING8 ? 1 : 0, out);
+}
+
+extern "C" int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out)
+{
+	if (f && f->kind != BTLBF_COUNTING8)
+		return fail(BTLBF_EINVAL, "filtered_popcount needs a counting filter");
+	return popcount_mode(f, 2, out);
+}
+
+// -------------------------------------------------------------------------------------------------
+// multi-GPU helpers
+// -------------------------------------------------------------------------------------------------
+extern "C" int btlbf_positions_seqs(btlbf_filter* f, const char* seq, uint64_t len,
+                                    const btlbf_layout* layout, unsigned n_shards, uint64_t* buckets,
+                                    uint64_t* tags, uint64_t bucket_cap, uint64_t* bucket_counts,
+                                    void* stream)
+{
+	int rc = seq_precheck(f, len);
+	if (rc)
+		return rc;
+	if (!buckets || !bucket_counts || n_shards == 0 || n_shards > 64)
+		return fail(BTLBF_EINVAL, "bad bucket arguments");
+	if (f->size % n_shards)
+		return fail(BTLBF_EINVAL, "size not divisible by n_shards");
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	SeqView v;
+	rc = make_view(v, seq, len, layout, BTLBF_DEVICE, s);
+	if (rc)
+		return rc;
+	SeqArgs a = base_args(f, v, len);
+	fill_mod(a.mod, f->size, 0, f->size / n_shards); // owner = position / (size/n_shards)
+	a.n_shards = n_shards;
+	a.buckets = buckets;
+	a.tags = tags;
+	a.bucket_cap = bucket_cap;
+	a.bucket_counts = reinterpret_cast<unsigned long long*>(bucket_counts);
+	HIP_TRY(hipMemsetAsync(bucket_counts, 0, (size_t)n_shards * 8, s));
+	HIP_TRY(launch_seq_op(OP_POSITIONS, a, s));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_insert_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n, void* stream)
+{
+	if (!f || (n && !local_pos))
+		return fail(BTLBF_EINVAL, "null argument");
+	if (f->kind != BTLBF_BLOOM)
+		return fail(BTLBF_EINVAL, "position routing is defined for bit filters");
+	DeviceGuard g(f->device);
+	HIP_TRY(launch_positions(0, f->d_data, f->mod, local_pos, n, nullptr, static_cast<hipStream_t>(stream)));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_test_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n, uint8_t* out,
+                                    void* stream)
+{
+	if (!f || (n && (!local_pos || !out)))
+		return fail(BTLBF_EINVAL, "null argument");
+	if (f->kind != BTLBF_BLOOM)
+		return fail(BTLBF_EINVAL, "position routing is defined for bit filters");
+	DeviceGuard g(f->device);
+	HIP_TRY(launch_positions(1, f->d_data, f->mod, local_pos, n, out, static_cast<hipStream_t>(stream)));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, unsigned hash_num,
+                                 uint64_t* hit_bits, int device, void* stream)
+{
+	if (n && (!tags || !answers || !hit_bits))
+		return fail(BTLBF_EINVAL, "null argument");
+	DeviceGuard g(device);
+	HIP_TRY(launch_and_answers(tags, answers, n, hash_num, hit_bits, static_cast<hipStream_t>(stream)));
+	return BTLBF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// support
+// -------------------------------------------------------------------------------------------------
+extern "C" int btlbf_synth_reads(char* dev_out, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                                 unsigned read_len, int device, void* stream)
+{
+	if (!dev_out || read_len == 0)
+		return fail(BTLBF_EINVAL, "bad argument");
+	DeviceGuard g(device);
+	HIP_TRY(launch_synth(reinterpret_cast<uint8_t*>(dev_out), seed, first_read, n_reads, read_len,
+	                     static_cast<hipStream_t>(stream)));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_microbench(btlbf_filter* f, int kind, uint64_t n_access, uint64_t* n_done,
+                                double* seconds)
+{
+	if (!f || !seconds || !n_done)
+		return fail(BTLBF_EINVAL, "null argument");
+	{
+		const uint64_t per_round = 2048ull * 256 * 8; // launch_microbench geometry
+		uint64_t rounds = n_access / per_round;
+		*n_done = (rounds ? rounds : 1) * per_round;
+	}
+	DeviceGuard g(f->device);
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipMemset(f->d_scalar, 0, 8));
+	HIP_TRY(hipEventRecord(e0, nullptr));
+	HIP_TRY(launch_microbench(f->d_data, f->local_bytes, kind, n_access, f->d_scalar, nullptr));
+	HIP_TRY(hipEventRecord(e1, nullptr));
+	HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	*seconds = ms * 1e-3;
+	return BTLBF_OK;
+}

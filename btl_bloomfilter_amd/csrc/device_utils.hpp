@@ -1,0 +1,131 @@
+// csrc/device_utils.hpp -- device-side arithmetic shared by the kernels (gfx950 only).
+#pragma once
+#include "internal.hpp"
+
+namespace btlbf {
+
+// One step of ntHash's split rotate: the low 33 bits and the high 31 bits of x each rotate left
+// by one (reference semantics: rol1 + swapbits033, vendor/nthash.hpp:350-352,377-380).
+__device__ __forceinline__ uint64_t srol1(uint64_t x)
+{
+	return ((x << 1) & ~((1ULL << 33) | 1ULL)) | ((x >> 32) & 1ULL) | ((x >> 30) & (1ULL << 33));
+}
+
+// Inverse step (ror1 + swapbits3263, vendor/nthash.hpp:361-363,383-386).
+__device__ __forceinline__ uint64_t sror1(uint64_t x)
+{
+	return ((x >> 1) & ~(1ULL << 32)) | ((x & 1ULL) << 32) | ((x & (1ULL << 33)) << 30);
+}
+
+// i-th extra hash of a canonical base hash (NTE64, vendor/nthash.hpp:537-542)
+__device__ __forceinline__ uint64_t extra_hash(uint64_t b, uint64_t kms, uint32_t i)
+{
+	uint64_t t = b * ((uint64_t)i ^ kms);
+	return t ^ (t >> kMultiShift);
+}
+
+// hash % size without a 64-bit divide: q = mulhi(hash, floor(2^64/size)) is the true quotient
+// or one less, so a single conditional subtract finishes (size >= 2).
+template <bool POW2>
+__device__ __forceinline__ uint64_t reduce_mod(uint64_t hash, const ModParams& m)
+{
+	if (POW2)
+		return hash & m.mask;
+	uint64_t q = __umul64hi(hash, m.magic);
+	uint64_t r = hash - q * m.size;
+	return r >= m.size ? r - m.size : r;
+}
+
+// ---- bit filter probes: bit (p%8) of byte p/8 == bit (p%32) of little-endian word p/32 --------
+__device__ __forceinline__ void bf_set(uint32_t* words, uint64_t lp)
+{
+	atomicOr(words + (lp >> 5), 1u << (lp & 31)); // result unused -> no-return global_atomic_or
+}
+__device__ __forceinline__ uint32_t bf_set_fetch(uint32_t* words, uint64_t lp)
+{
+	return (atomicOr(words + (lp >> 5), 1u << (lp & 31)) >> (lp & 31)) & 1u;
+}
+__device__ __forceinline__ uint32_t bf_word(const uint32_t* words, uint64_t lp)
+{
+	return words[lp >> 5];
+}
+
+// ---- uint8_t counters packed four to a word; HBM has no byte atomics, so CAS the word ----------
+__device__ __forceinline__ uint32_t agent_load(const uint32_t* p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t cbf_read_fresh(const uint32_t* words, uint64_t lp)
+{
+	return (agent_load(words + (lp >> 2)) >> ((lp & 3) * 8)) & 0xffu;
+}
+
+// saturating +1 (incrementAll's per-counter step, CountingBloomFilter.hpp:171-181)
+__device__ __forceinline__ void cbf_inc_sat(uint32_t* words, uint64_t lp)
+{
+	uint32_t* w = words + (lp >> 2);
+	const uint32_t sh = (lp & 3) * 8;
+	uint32_t old = agent_load(w);
+	for (;;) {
+		if (((old >> sh) & 0xffu) == 0xffu)
+			return; // "newVal < currentVal" overflow test: leave 255 alone
+		uint32_t prev = atomicCAS(w, old, old + (1u << sh));
+		if (prev == old)
+			return;
+		old = prev;
+	}
+}
+
+// byte CAS expect -> expect+1; returns true when this call made the change
+// (the __sync_bool_compare_and_swap of CountingBloomFilter.hpp:152)
+__device__ __forceinline__ bool cbf_cas_byte(uint32_t* words, uint64_t lp, uint32_t expect)
+{
+	uint32_t* w = words + (lp >> 2);
+	const uint32_t sh = (lp & 3) * 8;
+	uint32_t old = agent_load(w);
+	for (;;) {
+		if (((old >> sh) & 0xffu) != expect)
+			return false;
+		uint32_t prev = atomicCAS(w, old, old + (1u << sh));
+		if (prev == old)
+			return true;
+		old = prev;
+	}
+}
+
+// incrementMin (CountingBloomFilter.hpp:135-162) on local positions lp[0..h)
+template <int MAXH>
+__device__ __forceinline__ void cbf_increment_min(uint32_t* words, const uint64_t* lp, uint32_t h)
+{
+	for (;;) {
+		uint32_t mn = 0xffu;
+		for (uint32_t i = 0; i < h; ++i) {
+			uint32_t v = cbf_read_fresh(words, lp[i]);
+			mn = v < mn ? v : mn;
+		}
+		if (mn == 0xffu)
+			return; // minVal + 1 would wrap
+		bool done = false;
+		for (uint32_t i = 0; i < h; ++i)
+			done |= cbf_cas_byte(words, lp[i], mn);
+		if (done)
+			return;
+	}
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+	for (int o = 32; o > 0; o >>= 1)
+		v += __shfl_xor(v, o, 64);
+	return v;
+}
+
+} // namespace btlbf

@@ -1,0 +1,132 @@
+// csrc/internal.hpp -- parameter blocks shared by the HIP kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace btlbf {
+
+// ntHash constants (values: /root/reference/vendor/nthash.hpp:183-193; the pre-rotated
+// msTab31l/msTab33r tables at :230-347 are srol^s of these and are derived, not stored)
+static constexpr uint64_t kSeedA = 0x3c8bfbb395c60474ULL;
+static constexpr uint64_t kSeedC = 0x3193c18562a02b4cULL;
+static constexpr uint64_t kSeedG = 0x20323ed082572324ULL;
+static constexpr uint64_t kSeedT = 0x295549f54be24456ULL;
+static constexpr uint64_t kMultiSeed = 0x90b45d39fb6da1faULL;
+static constexpr unsigned kMultiShift = 27;
+
+// base codes used on the device: A=0 C=1 G=2 T=3, complement = code ^ 3
+// per-base byte staged in LDS: bits 1:0 code, bit 2 = valid base, bit 3 = first base of a sequence
+static constexpr unsigned kBaseValid = 4u;
+static constexpr unsigned kBaseStart = 8u;
+
+static constexpr int kMaxHash = 32;  // hash_num supported by the fused kernels
+static constexpr int kMaxSeeds = 16; // spaced seeds per filter
+
+// How positions are reduced modulo the filter size and mapped to this object's local array.
+struct ModParams {
+	uint64_t size;      // global modulus (bits or counters)
+	uint64_t magic;     // floor(2^64 / size) for the mulhi reduction (unused when pow2)
+	uint64_t mask;      // size-1 when pow2
+	uint64_t shard_lo;  // first global position held locally
+	uint64_t shard_len; // number of positions held locally (== size unless a shard)
+	uint32_t pow2;
+	uint32_t shard_shift; // log2(shard_len) if shard_len is a power of two else 0xffffffff
+};
+
+// Everything the hash stage needs.  Tables are tiny and copied to LDS by each workgroup.
+struct HashParams {
+	uint32_t k;
+	uint32_t h;        // hashes per window as seen by the filter (n_seeds*h2 when spaced)
+	uint32_t n_seeds;  // 0 = plain ntHash (ntHashIterator); >0 = spaced seeds (stHashIterator)
+	uint32_t h2;
+	uint64_t kms;      // k * multiSeed (nthash.hpp:585-589: multiplier is i ^ (k*multiSeed))
+	// per code c: {seed[c], srol^(k-1)(seed[c^3])}            -> Horner start-up of fh / rh
+	uint64_t init_tab[4][2];
+	// per code c: {seed[c], srol^k(seed[c^3])}                -> roll, incoming base
+	uint64_t in_tab[4][2];
+	// per code c: {srol^k(seed[c]), seed[c^3]}                -> roll, outgoing base
+	uint64_t out_tab[4][2];
+	// spaced seeds (device memory, owned by the filter / call):
+	//   pos_tab[i*4+c] = {srol^(k-1-i)(seed[c]), srol^i(seed[c^3])}, i<k
+	//   dc_idx = concatenated don't-care indices, seed j uses [dc_off[j], dc_off[j+1])
+	const uint64_t* pos_tab;
+	const uint16_t* dc_idx;
+	uint32_t dc_off[kMaxSeeds + 1];
+};
+
+// Sequence boundaries inside a buffer (btlbf_layout, device-resident form).
+struct LayoutParams {
+	const uint64_t* starts; // device pointer or nullptr
+	uint64_t n_seqs;
+	uint32_t read_len;
+};
+
+enum SeqOp : int {
+	OP_BF_INSERT = 0,
+	OP_BF_CONTAINS = 1,
+	OP_BF_INSERT_CHECK = 2,
+	OP_CBF_INC_MIN = 3,
+	OP_CBF_INC_ALL = 4,
+	OP_CBF_QUERY = 5,    // contains + optional min counts
+	OP_HASH_ONLY = 6,    // dense hashes / valid / strand output
+	OP_POSITIONS = 7     // bucket positions by owning shard (multi-GPU)
+};
+
+// operations on precomputed hash rows (aux_kernels.hip)
+enum HashOp : int {
+	H_BF_INSERT = 0,
+	H_BF_CONTAINS = 1,
+	H_BF_INSERT_CHECK = 2,
+	H_CBF_INC_MIN = 3,
+	H_CBF_INC_ALL = 4,
+	H_CBF_MIN = 5,      // out = min count
+	H_CBF_CONTAINS = 6, // out = min >= threshold
+	H_CBF_INSERT_CHECK = 7
+};
+
+struct SeqArgs {
+	const uint8_t* seq; // device
+	uint64_t len;
+	LayoutParams layout;
+	void* filter;       // device array (uint32 words for bloom, bytes for counting)
+	ModParams mod;
+	HashParams hp;
+	uint32_t threshold;
+	// outputs (device, optional)
+	uint8_t* hit_bits;    // byte view of the uint64_t bitmap
+	uint8_t* valid_bits;
+	uint64_t* counts;     // {clean windows, hits}
+	uint8_t* min_out;     // per window min count
+	uint64_t* hashes;     // OP_HASH_ONLY: len*h
+	uint64_t* strand_bits;
+	// OP_POSITIONS
+	uint32_t n_shards;
+	uint64_t* buckets;
+	uint64_t* tags;
+	uint64_t bucket_cap;
+	unsigned long long* bucket_counts;
+	// tiling
+	uint64_t n_tiles;
+	uint64_t tiles_per_block;
+};
+
+// launchers (defined in the .hip files)
+hipError_t launch_seq_op(int op, const SeqArgs& a, hipStream_t s);
+hipError_t launch_hash_op(int op, void* filter, const ModParams& mod, uint32_t h, uint32_t threshold,
+                          const uint64_t* hashes, uint64_t n, uint8_t* out, int serial, hipStream_t s);
+hipError_t launch_serial_seq_update(const SeqArgs& a, int op, const uint64_t* hashes,
+                                    const uint8_t* valid_bits, uint8_t* out, hipStream_t s);
+hipError_t launch_popcount(const void* data, uint64_t nbytes, int mode, uint32_t threshold,
+                           unsigned long long* out, hipStream_t s);
+hipError_t launch_synth(uint8_t* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t read_len,
+                        hipStream_t s);
+hipError_t launch_microbench(void* data, uint64_t nbytes, int kind, uint64_t n_access,
+                             unsigned long long* sink, hipStream_t s);
+hipError_t launch_positions(int test, void* filter, const ModParams& mod, const uint64_t* pos,
+                            uint64_t n, uint8_t* out, hipStream_t s);
+hipError_t launch_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, uint32_t h,
+                              uint64_t* hit_bits, hipStream_t s);
+
+int seq_tile_windows(); // windows per workgroup tile (for host-side sizing)
+
+} // namespace btlbf

@@ -1,0 +1,413 @@
+"""Host-side mirror of the reference's filter classes over the C ABI (include/btlbf.h).
+
+Method names follow the reference (insert / contains / insertAndCheck / storeFilter / getPop ...,
+/root/reference/BloomFilter.hpp:46-381, CountingBloomFilter.hpp:27-111) with batch arguments:
+sequence buffers (bytes / numpy uint8 / torch uint8 tensors on the GPU) or (n, h) uint64 hash rows.
+Buffers that are torch CUDA tensors are passed as device pointers; everything else is host memory
+that the library stages itself."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (BLOOM, COUNTING8, DEVICE, HOST, INCREMENT_ALL, INCREMENT_MIN, ORDER_PARALLEL,
+                   ORDER_SERIAL, Layout, check)
+
+
+def _is_torch_cuda(x):
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+
+
+class _Buf:
+    """pointer + length + memory space of a caller buffer; keeps the backing object alive"""
+
+    def __init__(self, x, dtype=np.uint8):
+        if _is_torch_cuda(x):
+            assert x.is_contiguous()
+            self.keep = x
+            self.ptr = C.c_void_p(x.data_ptr())
+            self.nbytes = x.numel() * x.element_size()
+            self.mem = DEVICE
+        else:
+            if isinstance(x, str):
+                x = x.encode("latin-1")
+            if isinstance(x, (bytes, bytearray, memoryview)):
+                x = np.frombuffer(bytes(x), dtype=np.uint8)
+            a = np.ascontiguousarray(x, dtype=dtype)
+            self.keep = a
+            self.ptr = C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
+            self.nbytes = a.nbytes
+            self.mem = HOST
+
+
+def _layout(starts, read_len, mem):
+    if starts is None and not read_len:
+        return None, None
+    lay = Layout()
+    keep = None
+    if starts is not None:
+        b = _Buf(starts, np.uint64)
+        if b.mem != mem:
+            raise ValueError("starts must live in the same memory space as the sequence buffer")
+        keep = b
+        lay.starts = b.ptr
+        lay.n_seqs = b.nbytes // 8 - 1
+        lay.read_len = 0
+    else:
+        lay.starts = None
+        lay.n_seqs = 0
+        lay.read_len = int(read_len)
+    return lay, keep
+
+
+def bits_to_bool(bits, n):
+    """per-window bitmap (uint64 words, bit p&63 of word p>>6) -> bool array of n windows"""
+    b = np.ascontiguousarray(bits).view(np.uint8)
+    return np.unpackbits(b, bitorder="little")[:n].astype(bool)
+
+
+def _bitmap(n):
+    return np.zeros((n + 63) // 64, np.uint64)
+
+
+class _Filter:
+    kind = BLOOM
+
+    def __init__(self, handle):
+        self._h = handle
+        self._L = _lib.load()
+
+    # -- lifetime --------------------------------------------------------------------------
+    @classmethod
+    def _create(cls, size, hash_num, kmer_size, threshold=0, device=0):
+        L = _lib.load()
+        h = C.c_void_p()
+        check(L.btlbf_create(C.byref(h), cls.kind, size, hash_num, kmer_size, threshold, device))
+        return cls(h)
+
+    @classmethod
+    def _load(cls, path, threshold=0, device=0):
+        L = _lib.load()
+        h = C.c_void_p()
+        check(L.btlbf_load(C.byref(h), cls.kind, str(path).encode(), threshold, device))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.btlbf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- attributes (reference getters) ------------------------------------------------------
+    def getHashNum(self):
+        return self._L.btlbf_hash_num(self._h)
+
+    def getKmerSize(self):
+        return self._L.btlbf_kmer_size(self._h)
+
+    def sizeInBytes(self):
+        return self._L.btlbf_size_bytes(self._h)
+
+    def localBytes(self):
+        return self._L.btlbf_local_bytes(self._h)
+
+    def device_ptr(self):
+        return self._L.btlbf_device_ptr(self._h)
+
+    def header(self):
+        n = C.c_size_t()
+        buf = C.create_string_buffer(1024)
+        check(self._L.btlbf_header(self._h, buf, 1024, C.byref(n)))
+        return buf.raw[: n.value]
+
+    def storeFilter(self, path):
+        check(self._L.btlbf_store(self._h, str(path).encode()))
+
+    def storeShard(self, path):
+        check(self._L.btlbf_store_shard(self._h, str(path).encode()))
+
+    def clear(self, stream=None):
+        check(self._L.btlbf_clear(self._h, _stream_ptr(stream)))
+
+    def download(self):
+        out = np.zeros(self.localBytes(), np.uint8)
+        check(self._L.btlbf_download(self._h, C.c_void_p(out.ctypes.data), 0, out.nbytes))
+        return out
+
+    def upload(self, body):
+        a = np.ascontiguousarray(body, np.uint8)
+        check(self._L.btlbf_upload(self._h, C.c_void_p(a.ctypes.data), 0, a.nbytes))
+
+    def setSpacedSeeds(self, seeds, h2=1):
+        arr = (C.c_char_p * len(seeds))(*[s.encode() if isinstance(s, str) else s for s in seeds])
+        check(self._L.btlbf_set_spaced_seeds(self._h, arr, len(seeds), h2))
+
+    # -- sequence buffers ----------------------------------------------------------------------
+    def _query(self, fn, seq, starts, read_len, want_valid, want_counts, stream):
+        b = _Buf(seq)
+        lay, keep = _layout(starts, read_len, b.mem)
+        n = b.nbytes
+        if b.mem == DEVICE:
+            import torch
+
+            hit = torch.zeros((n + 63) // 64, dtype=torch.int64, device=b.keep.device)
+            valid = torch.zeros_like(hit) if want_valid else None
+            cnt = torch.zeros(2, dtype=torch.int64, device=b.keep.device) if want_counts else None
+            ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        else:
+            hit = _bitmap(n)
+            valid = _bitmap(n) if want_valid else None
+            cnt = np.zeros(2, np.uint64) if want_counts else None
+            ptr = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None  # noqa: E731
+        check(fn(self._h, b.ptr, n, C.byref(lay) if lay else None, ptr(hit), ptr(valid), ptr(cnt), b.mem,
+                 _stream_ptr(stream)))
+        return hit, valid, cnt
+
+    def containsSeqs(self, seq, starts=None, read_len=0, want_valid=True, want_counts=False, stream=None):
+        """contains() of every window of a sequence buffer -> (hit_bits, valid_bits, counts)"""
+        return self._query(self._L.btlbf_contains_seqs, seq, starts, read_len, want_valid, want_counts, stream)
+
+    def _insert_seqs(self, seq, starts, read_len, op, order, stream):
+        b = _Buf(seq)
+        lay, keep = _layout(starts, read_len, b.mem)
+        check(self._L.btlbf_insert_seqs(self._h, b.ptr, b.nbytes, C.byref(lay) if lay else None, op, order,
+                                        b.mem, _stream_ptr(stream)))
+
+    # -- hash rows -----------------------------------------------------------------------------
+    def _rows(self, hashes):
+        h = self.getHashNum()
+        if _is_torch_cuda(hashes):
+            b = _Buf(hashes)
+            return b, b.nbytes // (8 * h)
+        a = np.ascontiguousarray(hashes, dtype=np.uint64).reshape(-1, h)
+        return _Buf(a, np.uint64), a.shape[0]
+
+    def _rows_out(self, fn, hashes, *extra, stream=None):
+        b, n = self._rows(hashes)
+        if b.mem == DEVICE:
+            import torch
+
+            out = torch.zeros(n, dtype=torch.uint8, device=b.keep.device)
+            optr = C.c_void_p(out.data_ptr())
+        else:
+            out = np.zeros(max(n, 1), np.uint8)
+            optr = C.c_void_p(out.ctypes.data)
+        check(fn(self._h, b.ptr, n, optr, *extra, b.mem, _stream_ptr(stream)))
+        return out[:n]
+
+
+class BloomFilter(_Filter):
+    """bit-array filter (reference: /root/reference/BloomFilter.hpp)"""
+
+    kind = BLOOM
+
+    def __init__(self, filterSize=None, hashNum=None, kmerSize=None, path=None, device=0, _handle=None):
+        if _handle is not None:
+            super().__init__(_handle)
+        elif path is not None:
+            super().__init__(type(self)._load(path, 0, device)._steal())
+        else:
+            super().__init__(type(self)._create(filterSize, hashNum, kmerSize, 0, device)._steal())
+
+    def _steal(self):
+        h, self._h = self._h, None
+        return h
+
+    @classmethod
+    def shard(cls, global_bits, shard_index, shard_count, hashNum, kmerSize, device=0):
+        L = _lib.load()
+        h = C.c_void_p()
+        check(L.btlbf_create_shard(C.byref(h), BLOOM, global_bits, shard_index, shard_count, hashNum, kmerSize,
+                                   0, device))
+        return cls(_handle=h)
+
+    def getFilterSize(self):
+        return self._L.btlbf_size(self._h)
+
+    def getnEntry(self):
+        return self._L.btlbf_get_n_entry(self._h)
+
+    def gettEntry(self):
+        return self._L.btlbf_get_t_entry(self._h)
+
+    def setnEntry(self, v):
+        self._L.btlbf_set_n_entry(self._h, v)
+
+    def settEntry(self, v):
+        self._L.btlbf_set_t_entry(self._h, v)
+
+    def getPop(self):
+        out = C.c_uint64()
+        check(self._L.btlbf_popcount(self._h, C.byref(out)))
+        return out.value
+
+    def getFPR(self):
+        return (self.getPop() / self.getFilterSize()) ** self.getHashNum()  # BloomFilter.hpp:346-350
+
+    # batch forms of insert / contains / insertAndCheck over hash rows
+    def insert(self, hashes, stream=None):
+        b, n = self._rows(hashes)
+        check(self._L.btlbf_insert_hashes(self._h, b.ptr, n, 0, ORDER_PARALLEL, b.mem, _stream_ptr(stream)))
+
+    def contains(self, hashes, stream=None):
+        return self._rows_out(self._L.btlbf_contains_hashes, hashes, stream=stream)
+
+    def insertAndCheck(self, hashes, serial=True, stream=None):
+        return self._rows_out(self._L.btlbf_insert_and_check_hashes, hashes,
+                              ORDER_SERIAL if serial else ORDER_PARALLEL, stream=stream)
+
+    # insertSeq (BloomFilterUtil.h:10) over whole buffers
+    def insertSeqs(self, seq, starts=None, read_len=0, stream=None):
+        self._insert_seqs(seq, starts, read_len, 0, ORDER_PARALLEL, stream)
+
+    def insertAndCheckSeqs(self, seq, starts=None, read_len=0, want_valid=True, want_counts=False, stream=None):
+        return self._query(self._L.btlbf_insert_and_check_seqs, seq, starts, read_len, want_valid, want_counts,
+                           stream)
+
+    def microbench(self, kind, n_access):
+        done = C.c_uint64()
+        sec = C.c_double()
+        check(self._L.btlbf_microbench(self._h, kind, n_access, C.byref(done), C.byref(sec)))
+        return done.value, sec.value
+
+
+class CountingBloomFilter(_Filter):
+    """uint8_t counting filter (reference: /root/reference/CountingBloomFilter.hpp, T = uint8_t)"""
+
+    kind = COUNTING8
+
+    def __init__(self, sizeInBytes=None, hashNum=None, kmerSize=None, countThreshold=0, path=None, device=0):
+        if path is not None:
+            t = type(self)._load(path, countThreshold, device)
+        else:
+            t = type(self)._create(sizeInBytes, hashNum, kmerSize, countThreshold, device)
+        h, t._h = t._h, None
+        super().__init__(h)
+
+    def size(self):
+        return self._L.btlbf_size(self._h)
+
+    def threshold(self):
+        return self._L.btlbf_threshold(self._h)
+
+    def popCount(self):
+        out = C.c_uint64()
+        check(self._L.btlbf_popcount(self._h, C.byref(out)))
+        return out.value
+
+    def filtered_popcount(self):
+        out = C.c_uint64()
+        check(self._L.btlbf_filtered_popcount(self._h, C.byref(out)))
+        return out.value
+
+    def FPR(self):
+        return (self.popCount() / self.size()) ** self.getHashNum()
+
+    def filtered_FPR(self):
+        return (self.filtered_popcount() / self.size()) ** self.getHashNum()
+
+    def insert(self, hashes, serial=False, stream=None):  # = incrementMin (CountingBloomFilter.hpp:198-204)
+        self.incrementMin(hashes, serial, stream)
+
+    def incrementMin(self, hashes, serial=False, stream=None):
+        b, n = self._rows(hashes)
+        check(self._L.btlbf_insert_hashes(self._h, b.ptr, n, INCREMENT_MIN,
+                                          ORDER_SERIAL if serial else ORDER_PARALLEL, b.mem, _stream_ptr(stream)))
+
+    def incrementAll(self, hashes, serial=False, stream=None):
+        b, n = self._rows(hashes)
+        check(self._L.btlbf_insert_hashes(self._h, b.ptr, n, INCREMENT_ALL,
+                                          ORDER_SERIAL if serial else ORDER_PARALLEL, b.mem, _stream_ptr(stream)))
+
+    def minCount(self, hashes, stream=None):
+        return self._rows_out(self._L.btlbf_min_count_hashes, hashes, stream=stream)
+
+    def contains(self, hashes, stream=None):
+        return self._rows_out(self._L.btlbf_contains_hashes, hashes, stream=stream)
+
+    def insertAndCheck(self, hashes, serial=True, stream=None):
+        return self._rows_out(self._L.btlbf_insert_and_check_hashes, hashes,
+                              ORDER_SERIAL if serial else ORDER_PARALLEL, stream=stream)
+
+    def insertSeqs(self, seq, starts=None, read_len=0, increment_all=False, serial=False, stream=None):
+        self._insert_seqs(seq, starts, read_len, INCREMENT_ALL if increment_all else INCREMENT_MIN,
+                          ORDER_SERIAL if serial else ORDER_PARALLEL, stream)
+
+    def minCountSeqs(self, seq, starts=None, read_len=0, stream=None):
+        b = _Buf(seq)
+        lay, keep = _layout(starts, read_len, b.mem)
+        n = b.nbytes
+        if b.mem == DEVICE:
+            import torch
+
+            mn = torch.zeros(n, dtype=torch.uint8, device=b.keep.device)
+            valid = torch.zeros((n + 63) // 64, dtype=torch.int64, device=b.keep.device)
+            p1, p2 = C.c_void_p(mn.data_ptr()), C.c_void_p(valid.data_ptr())
+        else:
+            mn = np.zeros(max(n, 1), np.uint8)
+            valid = _bitmap(n)
+            p1, p2 = C.c_void_p(mn.ctypes.data), C.c_void_p(valid.ctypes.data)
+        check(self._L.btlbf_min_count_seqs(self._h, b.ptr, n, C.byref(lay) if lay else None, p1, p2, b.mem,
+                                           _stream_ptr(stream)))
+        return mn[:n], valid
+
+
+def _hash_seqs(seq, k, h, seeds, h2, starts, read_len, device, stream):
+    L = _lib.load()
+    b = _Buf(seq)
+    lay, keep = _layout(starts, read_len, b.mem)
+    n = b.nbytes
+    sarr = None
+    ns = 0
+    if seeds is not None:
+        ns = len(seeds)
+        sarr = (C.c_char_p * ns)(*[s.encode() if isinstance(s, str) else s for s in seeds])
+    if b.mem == DEVICE:
+        import torch
+
+        hv = torch.zeros((n, h), dtype=torch.int64, device=b.keep.device)
+        valid = torch.zeros((n + 63) // 64, dtype=torch.int64, device=b.keep.device)
+        st = torch.zeros(n, dtype=torch.int64, device=b.keep.device) if seeds is not None else None
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    else:
+        hv = np.zeros((max(n, 1), h), np.uint64)
+        valid = _bitmap(n)
+        st = np.zeros(max(n, 1), np.uint64) if seeds is not None else None
+        ptr = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None  # noqa: E731
+    check(L.btlbf_hash_seqs(k, h, sarr, ns, h2, b.ptr, n, C.byref(lay) if lay else None, ptr(hv), ptr(valid),
+                            ptr(st), b.mem, device, _stream_ptr(stream)))
+    return hv[:n], valid, (st[:n] if st is not None else None)
+
+
+def hash_seqs(seq, h, k, starts=None, read_len=0, device=0, stream=None):
+    """ntHashIterator(seq, h, k) over a whole buffer (vendor/ntHashIterator.hpp:38):
+    -> (hashes[n, h], valid_bits).  Window p is emitted by the iterator iff its valid bit is set."""
+    hv, valid, _ = _hash_seqs(seq, k, h, None, 0, starts, read_len, device, stream)
+    return hv, valid
+
+
+def sthash_seqs(seq, seeds, h2, k, starts=None, read_len=0, device=0, stream=None):
+    """stHashIterator(seq, parseSeed(seeds), len(seeds), h2, k) (vendor/stHashIterator.hpp:53):
+    -> (hashes[n, len(seeds)*h2], valid_bits, strand_bits[n])"""
+    return _hash_seqs(seq, k, len(seeds) * h2, seeds, h2, starts, read_len, device, stream)
+
+
+def synth_reads_device(seed, first, n_reads, read_len, device=0, stream=None):
+    """synthetic reads of SURVEY.md 8d generated in HBM -> torch uint8 tensor (n_reads*read_len)"""
+    import torch
+
+    out = torch.empty(n_reads * read_len, dtype=torch.uint8, device="cuda:%d" % device)
+    check(_lib.load().btlbf_synth_reads(C.c_void_p(out.data_ptr()), seed, first, n_reads, read_len, device,
+                                        _stream_ptr(stream)))
+    return out

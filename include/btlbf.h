@@ -1,0 +1,208 @@
+/* include/btlbf.h -- C ABI of the MI355X-native k-mer Bloom filter engine.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  The C++ shims
+ * in include/btlbf/ (same class names and methods as the reference's public headers) and the
+ * Python host code in btl_bloomfilter_amd/ are thin callers of these entry points; every entry
+ * point that computes runs hand-written HIP kernels for gfx950 (btl_bloomfilter_amd/csrc/).
+ * There is no CPU fallback: on a machine without a usable GPU the compute calls return
+ * BTLBF_EHIP and btlbf_last_error() says why.
+ *
+ * The reference (bcgsc/btl_bloomfilter, /root/reference) has no FFI layer; its boundary is its
+ * C++ header API.  Each entry below cites the reference interface it replaces (file:line).
+ *
+ * Conventions
+ *  - every function returns 0 (BTLBF_OK) or a BTLBF_E* code; btlbf_last_error() (thread-local)
+ *    holds a message for the last failure on the calling thread.
+ *  - `mem` says where the caller's buffers live: BTLBF_HOST (pageable/pinned host memory; the
+ *    library stages through its own device scratch) or BTLBF_DEVICE (HBM pointers, used as-is).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work on one filter
+ *    is ordered by the stream; BTLBF_HOST calls synchronise before returning.
+ *  - a "sequence buffer" is `len` bytes of nucleotide text.  Windows (k-mers) are identified by
+ *    the byte offset p of their first base.  A window is *clean* iff all k bytes are bases the
+ *    reference accepts (seedTab != 0, vendor/nthash.hpp:195-228: A C G T U, either case, and
+ *    the raw bytes 1 3 4 5 7) and it does not cross a sequence boundary.  Exactly the clean
+ *    windows are the k-mers ntHashIterator emits (vendor/ntHashIterator.hpp:59-86).
+ *  - sequence boundaries inside a buffer are described by a btlbf_layout:
+ *      starts != NULL : n_seqs+1 ascending byte offsets (starts[0]=0 .. starts[n_seqs]=len)
+ *      else read_len>0: back-to-back reads of exactly read_len bytes (len % read_len == 0)
+ *      else           : the whole buffer is one sequence
+ *    `starts` lives in the same memory space as the sequence buffer.
+ *  - per-window results are bitmaps of ceil(len/64) uint64_t words: bit (p & 63) of word p >> 6
+ *    belongs to the window starting at byte p; windows that are not clean report 0.
+ */
+#ifndef BTLBF_H
+#define BTLBF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct btlbf_filter btlbf_filter; /* opaque; owns its HBM array (BloomFilter.hpp:381,398) */
+
+enum { BTLBF_HOST = 0, BTLBF_DEVICE = 1 };
+enum { BTLBF_BLOOM = 0, BTLBF_COUNTING8 = 1 };
+enum {
+	BTLBF_OK = 0,
+	BTLBF_EINVAL = 1,  /* bad argument (e.g. bit count not a multiple of 8, BloomFilter.hpp:391-394) */
+	BTLBF_ENOMEM = 2,
+	BTLBF_EIO = 3,     /* file could not be opened/read/written (vendor/IOUtil.h:14-22) */
+	BTLBF_EFORMAT = 4, /* bad magic line / missing [HeaderEnd] / missing key (BloomFilter.hpp:123-148) */
+	BTLBF_EHIP = 5     /* HIP runtime error, or no GPU */
+};
+/* counting-filter update flavours (CountingBloomFilter.hpp:135-183) */
+enum { BTLBF_INCREMENT_MIN = 0, BTLBF_INCREMENT_ALL = 1 };
+/* BTLBF_ORDER_SERIAL applies k-mers one after another in buffer order on a single lane: the only
+ * way incrementMin is reproducible (it is order-dependent). */
+enum { BTLBF_ORDER_PARALLEL = 0, BTLBF_ORDER_SERIAL = 1 };
+
+typedef struct btlbf_layout {
+	const uint64_t* starts; /* n_seqs+1 offsets, or NULL */
+	uint64_t n_seqs;        /* used with starts */
+	uint32_t read_len;      /* used when starts == NULL; 0 = one sequence */
+} btlbf_layout;
+
+const char* btlbf_last_error(void);
+int btlbf_device_count(void); /* number of visible GPUs, 0 if none (never fails) */
+
+/* ---- lifetime ------------------------------------------------------------------------------
+ * BTLBF_BLOOM:     `size` = number of bits, must be a multiple of 8
+ *                  (BloomFilter(size_t,unsigned,unsigned), BloomFilter.hpp:65-76,389-399)
+ * BTLBF_COUNTING8: `size` = bytes requested, rounded up to a multiple of 8; one uint8_t counter
+ *                  per byte (CountingBloomFilter<uint8_t>(size_t,unsigned,unsigned,unsigned),
+ *                  CountingBloomFilter.hpp:31-50).  `threshold` is ignored for BTLBF_BLOOM.
+ * The array is allocated in the HBM of `device` and zeroed. */
+int btlbf_create(btlbf_filter** out, int kind, uint64_t size, unsigned hash_num, unsigned kmer_size,
+                 unsigned threshold, int device);
+/* One hash-range shard of a larger filter: positions are computed modulo
+ * `global_size` and this object stores [shard_index*global_size/shard_count, +global_size/shard_count).
+ * Concatenating the shard bodies in index order is the single-filter body. */
+int btlbf_create_shard(btlbf_filter** out, int kind, uint64_t global_size, unsigned shard_index,
+                       unsigned shard_count, unsigned hash_num, unsigned kmer_size,
+                       unsigned threshold, int device);
+int btlbf_destroy(btlbf_filter* f); /* ~BloomFilter, BloomFilter.hpp:381 */
+
+/* ---- BTLBloomFilter_v1 / BTLCountingBloomFilter_v1 files ------------------------------------
+ * load:  BloomFilter(const string&) BloomFilter.hpp:101-116,118-166;
+ *        CountingBloomFilter(const string&, unsigned) CountingBloomFilter.hpp:262-343
+ * store: storeFilter BloomFilter.hpp:304-314 / CountingBloomFilter.hpp:331-342; the header bytes
+ *        are those the reference writes (key order, tab indent, %#.17g doubles) */
+int btlbf_load(btlbf_filter** out, int kind, const char* path, unsigned threshold, int device);
+int btlbf_store(btlbf_filter* f, const char* path);
+/* header text only (writeHeader BloomFilter.hpp:264-288, storeHeader CountingBloomFilter.hpp:344-368) */
+int btlbf_header(const btlbf_filter* f, char* buf, size_t cap, size_t* len);
+/* shard-aware store: shard 0 writes header+body at offset 0, shard s writes its body at
+ * header_len + s*shard_bytes of the same file (SURVEY.md section 5 "Checkpoint / resume") */
+int btlbf_store_shard(btlbf_filter* f, const char* path);
+
+/* ---- attributes (getters of BloomFilter.hpp:325-327,369-379; CountingBloomFilter.hpp:78-82) -- */
+int btlbf_kind(const btlbf_filter* f);
+uint64_t btlbf_size(const btlbf_filter* f);        /* getFilterSize() bits / size() counters (global) */
+uint64_t btlbf_size_bytes(const btlbf_filter* f);  /* sizeInBytes() (global) */
+uint64_t btlbf_local_bytes(const btlbf_filter* f); /* bytes held by this object (== size_bytes unless a shard) */
+unsigned btlbf_hash_num(const btlbf_filter* f);
+unsigned btlbf_kmer_size(const btlbf_filter* f);
+unsigned btlbf_threshold(const btlbf_filter* f);
+uint64_t btlbf_get_n_entry(const btlbf_filter* f);
+uint64_t btlbf_get_t_entry(const btlbf_filter* f);
+void btlbf_set_n_entry(btlbf_filter* f, uint64_t v); /* setnEntry BloomFilter.hpp:373 */
+void btlbf_set_t_entry(btlbf_filter* f, uint64_t v); /* settEntry BloomFilter.hpp:375 */
+void* btlbf_device_ptr(const btlbf_filter* f);       /* the HBM array */
+int btlbf_device(const btlbf_filter* f);
+
+/* raw array access; offset/nbytes in bytes of the local array */
+int btlbf_clear(btlbf_filter* f, void* stream);
+int btlbf_upload(btlbf_filter* f, const void* host_src, uint64_t offset, uint64_t nbytes);
+int btlbf_download(const btlbf_filter* f, void* host_dst, uint64_t offset, uint64_t nbytes);
+
+/* Use spaced-seed hashing (stHashIterator, vendor/stHashIterator.hpp:23-33,53-57) for every
+ * sequence-buffer call on this filter: `seeds` are n_seeds strings of length kmer_size, '1' =
+ * care; hash_num must equal n_seeds*h2.  Without this call sequences are hashed like
+ * ntHashIterator (vendor/ntHashIterator.hpp:38). */
+int btlbf_set_spaced_seeds(btlbf_filter* f, const char* const* seeds, unsigned n_seeds, unsigned h2);
+
+/* ---- the hot path: hash every clean window of a sequence buffer and probe the filter --------
+ * insert:   insertSeq (BloomFilterUtil.h:9-17) = ntHashIterator + BloomFilter::insert
+ *           (BloomFilter.hpp:185-194); counting filters: CountingBloomFilter::insert =
+ *           incrementMin (CountingBloomFilter.hpp:198-204) or incrementAll (:165-183) per `op`.
+ * contains: ntHashIterator + BloomFilter::contains (BloomFilter.hpp:252-262) /
+ *           CountingBloomFilter::contains (CountingBloomFilter.hpp:190-196).
+ * insert_and_check: BloomFilter::insertAndCheck (BloomFilter.hpp:200-214) -- bit of window p =
+ *           all h bits were already set before this window's own writes.
+ * hit_bits / valid_bits may be NULL.  counts (may be NULL) receives {clean windows, hits}; it
+ * lives in `mem` space and is overwritten. */
+int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
+                      int op, int order, int mem, void* stream);
+int btlbf_contains_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
+                        uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts, int mem,
+                        void* stream);
+int btlbf_insert_and_check_seqs(btlbf_filter* f, const char* seq, uint64_t len,
+                                const btlbf_layout* layout, uint64_t* hit_bits, uint64_t* valid_bits,
+                                uint64_t* counts, int mem, void* stream);
+/* minCount per window (CountingBloomFilter.hpp:53-64): min_out[p], len bytes, 0 for unclean windows */
+int btlbf_min_count_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
+                         uint8_t* min_out, uint64_t* valid_bits, int mem, void* stream);
+
+/* ---- precomputed hashes: n k-mers x hash_num uint64_t, row-major ------------------------------
+ * insert(const uint64_t[]) BloomFilter.hpp:185; contains(const uint64_t[]) :252;
+ * insertAndCheck(const uint64_t[]) :200; CountingBloomFilter insert/incrementAll/minCount/contains */
+int btlbf_insert_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, int op, int order,
+                        int mem, void* stream);
+int btlbf_contains_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, uint8_t* out, int mem,
+                          void* stream);
+int btlbf_insert_and_check_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, uint8_t* out,
+                                  int order, int mem, void* stream);
+int btlbf_min_count_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, uint8_t* min_out,
+                           int mem, void* stream);
+
+/* ---- hash streams only (iterator parity) -------------------------------------------------------
+ * ntHashIterator (vendor/ntHashIterator.hpp:38,93): hashes[p*h .. p*h+h) for window p (zeros when
+ * not clean), valid_bits as above.  With seeds != NULL: stHashIterator(seq, seeds, n_seeds, h2, k)
+ * (vendor/stHashIterator.hpp:53,94-103), h = n_seeds*h2 values per window and strand_bits[p] bit j =
+ * strandArray()[j] (h <= 64 in that case).  Buffers live in `mem` space. */
+int btlbf_hash_seqs(unsigned kmer_size, unsigned hash_num, const char* const* seeds, unsigned n_seeds,
+                    unsigned h2, const char* seq, uint64_t len, const btlbf_layout* layout,
+                    uint64_t* hashes, uint64_t* valid_bits, uint64_t* strand_bits, int mem,
+                    int device, void* stream);
+
+/* ---- statistics --------------------------------------------------------------------------------
+ * getPop BloomFilter.hpp:316-323 (set bits); counting: popCount (non-zero counters) :217-228 and
+ * filtered_popcount (counters >= threshold) :231-242.  Local array only for shards. */
+int btlbf_popcount(btlbf_filter* f, uint64_t* out);
+int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out);
+
+/* ---- multi-GPU hash-range sharding ------------------------------------------------
+ * positions_seqs: hash the buffer and, instead of probing, append each probe's filter position to
+ * the bucket of its owning shard.  buckets = n_shards regions of `bucket_cap` uint64_t each in one
+ * device array; bucket_counts[n_shards] (device, zeroed by the call) receives the fill.  Entry =
+ * position local to the owning shard, with (window_id << 40 | probe slot...) NOT encoded: for
+ * queries the parallel array `tags` (same shape, may be NULL) receives the probe id
+ * (window offset p * hash_num + i) so that answers can be routed back.
+ * insert_positions / test_positions act on local positions of this shard. */
+int btlbf_positions_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
+                         unsigned n_shards, uint64_t* buckets, uint64_t* tags, uint64_t bucket_cap,
+                         uint64_t* bucket_counts, void* stream);
+int btlbf_insert_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n, void* stream);
+/* out_bits: one byte per position (0/1) */
+int btlbf_test_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n, uint8_t* out,
+                         void* stream);
+/* origin side of a sharded query: AND the returned probe answers into per-window results.
+ * answers[i] belongs to probe tags[i]; hit_bits must have been initialised with the valid bits. */
+int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, unsigned hash_num,
+                      uint64_t* hit_bits, int device, void* stream);
+
+/* ---- support ------------------------------------------------------------------------------------
+ * synthetic reads of SURVEY.md 8d written to device memory: n reads x read_len bytes */
+int btlbf_synth_reads(char* dev_out, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                      unsigned read_len, int device, void* stream);
+/* bare random-access ceilings on the filter's own array (SURVEY.md 8d "measured ceiling"):
+ * kind 0 = independent 4-byte loads, 1 = 4-byte atomicOr (sets bits: clear the filter afterwards),
+ * at uniformly random 64-byte-aligned offsets; about n_access accesses, the exact number is
+ * returned in *n_done; *seconds = kernel time from HIP events */
+int btlbf_microbench(btlbf_filter* f, int kind, uint64_t n_access, uint64_t* n_done, double* seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTLBF_H */

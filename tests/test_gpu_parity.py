@@ -1,0 +1,430 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the golden vectors of the
+genuine reference and against the CPU oracle on seeded random inputs.  Bit-exact everywhere
+(integer work)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bf():
+    import btl_bloomfilter_amd as m
+
+    assert m._lib.load().btlbf_device_count() > 0, "GPU tests need a GPU (and the HIP library)"
+    return m
+
+
+def unhex(lst, cols):
+    a = np.array([int(x, 16) for x in lst], dtype=np.uint64)
+    return a.reshape(-1, cols) if cols else a
+
+
+def rand_seq(rng, n, p_bad=0.02):
+    s = rng.choice(list(b"ACGTacgt"), n).astype(np.uint8)
+    bad = rng.rand(n) < p_bad
+    s[bad] = rng.choice(list(b"NnRY-\x00\x01\x07\xff"), bad.sum())
+    return s.tobytes()
+
+
+def emitted(hv, valid_bits, n, k):
+    nw = max(n - k + 1, 0)
+    v = __import__("btl_bloomfilter_amd").bits_to_bool(valid_bits, n)
+    assert not v[nw:].any(), "window beyond the end of the buffer reported clean"
+    pos = np.flatnonzero(v)
+    return pos, np.asarray(hv)[pos]
+
+
+# ---------------------------------------------------------------------------------------------
+# hash streams
+# ---------------------------------------------------------------------------------------------
+def test_g1_nthash_golden(bf):
+    g = load_golden("hash_vectors.json")["nthash"]
+    nk = 0
+    for case in g:
+        s = case["seq"].encode("latin-1")
+        if not s:
+            continue
+        hv, valid = bf.hash_seqs(s, case["h"], case["k"])
+        pos, hh = emitted(hv, valid, len(s), case["k"])
+        assert pos.tolist() == case["pos"], (case["seq"][:20], case["k"])
+        assert (hh == unhex(case["hashes"], case["h"])).all()
+        nk += len(pos)
+    assert nk > 10000
+
+
+def test_g2_sthash_golden(bf):
+    for case in load_golden("hash_vectors.json")["sthash"]:
+        s = case["seq"].encode("latin-1")
+        m = len(case["seeds"]) * case["h2"]
+        hv, valid, st = bf.sthash_seqs(s, case["seeds"], case["h2"], case["k"])
+        pos, hh = emitted(hv, valid, len(s), case["k"])
+        assert pos.tolist() == case["pos"]
+        assert (hh == unhex(case["hashes"], m)).all()
+        strand = ((np.asarray(st)[pos][:, None] >> np.arange(m, dtype=np.uint64)) & np.uint64(1)).ravel()
+        assert strand.tolist() == case["strand"]
+
+
+@pytest.mark.parametrize("k,h", [(1, 1), (4, 5), (25, 3), (31, 4), (32, 2), (64, 4), (150, 2), (301, 1)])
+def test_nthash_random_vs_oracle(bf, oracle, k, h):
+    rng = np.random.RandomState(k * 7 + h)
+    for n in (1, k - 1, k, k + 1, 2047, 2048, 2049, 2048 + k - 1, 5000, 40000):
+        if n <= 0:
+            continue
+        s = rand_seq(rng, n, p_bad=rng.choice([0, 0.003, 0.05]))
+        hv, valid = bf.hash_seqs(s, h, k)
+        pos, hh = emitted(hv, valid, n, k)
+        op, oh = oracle.nthash_seq(s, h, k)
+        assert pos.tolist() == op.tolist(), (n, k)
+        assert (hh == oh).all()
+
+
+def test_layouts_ragged_uniform_and_misaligned_device_pointers(bf, oracle):
+    import torch
+
+    rng = np.random.RandomState(11)
+    k, h = 31, 4
+    lens = [0, 5, 30, 31, 32, 150, 150, 1, 2047, 2048, 4100, 0, 77, 31]
+    reads = [rand_seq(rng, n, 0.01) for n in lens]
+    buf = b"".join(reads)
+    starts = np.cumsum([0] + lens).astype(np.uint64)
+    exp_pos, exp_h = [], []
+    for st, r in zip(starts, reads):
+        p, hv = oracle.nthash_seq(r, h, k)
+        exp_pos += (p + st).tolist()
+        exp_h.append(hv)
+    exp_h = np.concatenate(exp_h)
+    # host, ragged
+    hv, valid = bf.hash_seqs(buf, h, k, starts=starts)
+    pos, hh = emitted(hv, valid, len(buf), k)
+    assert pos.tolist() == exp_pos and (hh == exp_h).all()
+    # device, ragged, every misalignment of the base pointer
+    for mis in (0, 1, 3, 8, 15):
+        t = torch.zeros(len(buf) + 32, dtype=torch.uint8, device="cuda")
+        t[mis:mis + len(buf)] = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+        ts = torch.from_numpy(starts.astype(np.int64)).cuda()
+        hv, valid = bf.hash_seqs(t[mis:mis + len(buf)], h, k, starts=ts)
+        torch.cuda.synchronize()
+        pos, hh = emitted(hv.cpu().numpy().view(np.uint64), valid.cpu().numpy().view(np.uint64), len(buf), k)
+        assert pos.tolist() == exp_pos and (hh == exp_h).all(), mis
+    # uniform reads of several lengths (including shorter than k and not a multiple of anything)
+    for L in (150, 31, 30, 7, 100, 2048, 3000):
+        n_reads = max(3, 9000 // L)
+        rs = [rand_seq(rng, L, 0.01) for _ in range(n_reads)]
+        exp_pos, exp_h = [], []
+        for i, r in enumerate(rs):
+            p, hv = oracle.nthash_seq(r, h, k)
+            exp_pos += (p + i * L).tolist()
+            exp_h.append(hv)
+        hv, valid = bf.hash_seqs(b"".join(rs), h, k, read_len=L)
+        pos, hh = emitted(hv, valid, L * n_reads, k)
+        assert pos.tolist() == exp_pos, L
+        assert (hh == np.concatenate(exp_h)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# bit filter
+# ---------------------------------------------------------------------------------------------
+def test_g3_bloom_files_whole_bytes(bf, tmp_path):
+    for f in load_golden("files.json"):
+        if f["kind"] != "bloom":
+            continue
+        flt = bf.BloomFilter(f["bits"], f["h"], f["k"])
+        for s in f["inserted"]:
+            flt.insertSeqs(s)
+        flt.setnEntry(f["n_entry"])
+        flt.settEntry(f["t_entry"])
+        p = tmp_path / f["file"]
+        flt.storeFilter(p)
+        raw = open(os.path.join(GOLDEN, f["file"]), "rb").read()
+        assert open(p, "rb").read() == raw, f["file"]
+        assert flt.getPop() == f["pop"]
+        # the reference's own file loads and answers like the filter that wrote it
+        g = bf.BloomFilter(path=os.path.join(GOLDEN, f["file"]))
+        assert (g.getFilterSize(), g.getHashNum(), g.getKmerSize()) == (f["bits"], f["h"], f["k"])
+        assert (g.getnEntry(), g.gettEntry()) == (f["n_entry"], f["t_entry"])
+        assert (g.download() == flt.download()).all()
+        for s in f["inserted"]:
+            hit, valid, _ = g.containsSeqs(s)
+            assert (bf.bits_to_bool(hit, len(s)) == bf.bits_to_bool(valid, len(s))).all()
+
+
+def test_g5_contains_bitmasks(bf):
+    ops = load_golden("filter_ops.json")
+    for key in ("contains_65536", "contains_100000"):
+        g = ops[key]
+        flt = bf.BloomFilter(g["bits"], g["h"], g["k"])
+        buf = "".join(g["A"]).encode()
+        flt.insertSeqs(buf, read_len=150)
+        body = flt.download()
+        assert hashlib.sha256(body.tobytes()).hexdigest() == g["body_sha256"]
+        assert flt.getPop() == g["pop"]
+        for s, r in zip(g["B"], g["result"]):
+            hit, valid, cnt = flt.containsSeqs(s, want_counts=True)
+            v = bf.bits_to_bool(valid, len(s))
+            hbits = bf.bits_to_bool(hit, len(s))
+            assert np.flatnonzero(v).tolist() == r["pos"]
+            assert hbits[v].astype(int).tolist() == r["hit"]
+            assert cnt.tolist() == [len(r["pos"]), sum(r["hit"])]
+        # all reads of B in one ragged call
+        lens = [len(s) for s in g["B"]]
+        starts = np.cumsum([0] + lens).astype(np.uint64)
+        hit, valid, _ = flt.containsSeqs("".join(g["B"]).encode(), starts=starts)
+        hb, vb = bf.bits_to_bool(hit, starts[-1]), bf.bits_to_bool(valid, starts[-1])
+        for st, s, r in zip(starts, g["B"], g["result"]):
+            st = int(st)
+            assert (np.flatnonzero(vb[st:st + len(s)])).tolist() == r["pos"]
+            assert hb[st:st + len(s)][vb[st:st + len(s)]].astype(int).tolist() == r["hit"]
+
+
+def test_g6_insert_and_check(bf, oracle):
+    g = load_golden("filter_ops.json")["insert_and_check"]
+    flt = bf.BloomFilter(g["bits"], g["h"], g["k"])
+    for s, r in zip(g["stream"], g["result"]):
+        _, hv = oracle.nthash_seq(s, g["h"], g["k"])
+        assert flt.insertAndCheck(hv, serial=True).tolist() == r
+    assert hashlib.sha256(flt.download().tobytes()).hexdigest() == g["body_sha256"]
+    # sequence form on a buffer without repeated k-mers: parallel order cannot matter
+    flt2 = bf.BloomFilter(g["bits"], g["h"], g["k"])
+    s = g["stream"][0]
+    hit, valid, _ = flt2.insertAndCheckSeqs(s)
+    assert bf.bits_to_bool(hit, len(s))[bf.bits_to_bool(valid, len(s))].astype(int).tolist() == g["result"][0]
+    hit, valid, _ = flt2.insertAndCheckSeqs(s)
+    assert (bf.bits_to_bool(hit, len(s)) == bf.bits_to_bool(valid, len(s))).all()
+
+
+def test_g8_modulo_edges(bf):
+    for g in load_golden("filter_ops.json")["modulo"]:
+        flt = bf.BloomFilter(g["size"], 1, 4)
+        flt.insert(unhex(g["hashes"], 1))
+        bits = np.flatnonzero(np.unpackbits(flt.download(), bitorder="little"))
+        assert bits.tolist() == g["set_bits"], g["size"]
+        assert flt.contains(unhex(g["hashes"], 1)).all()
+
+
+@pytest.mark.parametrize("bits", [64, 1000, 4096, 999992, 1 << 20, (1 << 20) + 8])
+def test_hash_rows_random_vs_oracle(bf, oracle, bits):
+    rng = np.random.RandomState(bits % 1000)
+    h = 5
+    hv = rng.randint(0, 2 ** 63, size=(3000, h)).astype(np.uint64) * np.uint64(2) + rng.randint(0, 2, size=(3000, h)).astype(np.uint64)
+    flt = bf.BloomFilter(bits, h, 20)
+    mine = np.zeros(bits // 8, np.uint8)
+    flt.insert(hv[:1500])
+    oracle.bf_insert(mine, bits, h, hv[:1500])
+    assert (flt.download() == mine).all()
+    assert flt.contains(hv).tolist() == oracle.bf_contains(mine, bits, h, hv).tolist()
+    assert flt.insertAndCheck(hv[1000:2000], serial=True).tolist() == oracle.bf_insert_and_check(mine, bits, h, hv[1000:2000]).tolist()
+    assert (flt.download() == mine).all()
+    assert flt.getPop() == oracle.bf_popcount(mine, bits)
+
+
+@pytest.mark.parametrize("k,h,bits", [(31, 4, 1 << 22), (25, 3, 3000000), (8, 7, 1 << 16), (64, 2, 1 << 20)])
+def test_insert_contains_seqs_random_vs_oracle(bf, oracle, k, h, bits):
+    rng = np.random.RandomState(k + h)
+    a = rand_seq(rng, 30000, 0.004)
+    b = a[:9000] + rand_seq(rng, 9000, 0.004)
+    flt = bf.BloomFilter(bits, h, k)
+    flt.insertSeqs(a)
+    mine = np.zeros(bits // 8, np.uint8)
+    oracle.bf_insert_seq(mine, bits, h, k, a)
+    assert (flt.download() == mine).all()
+    hit, valid, cnt = flt.containsSeqs(b, want_counts=True)
+    ohit, ovalid = oracle.bf_contains_seq_dense(mine, bits, h, k, b)
+    nw = len(b) - k + 1
+    assert (bf.bits_to_bool(valid, len(b))[:nw] == ovalid.astype(bool)).all()
+    assert (bf.bits_to_bool(hit, len(b))[:nw] == ohit.astype(bool)).all()
+    assert cnt.tolist() == [int(ovalid.sum()), int(ohit.sum())]
+
+
+def test_reference_unit_test_bloom(bf, tmp_path):
+    # mirrors Tests/Unit/BloomFilterTests.cpp:69-139 (1e9-bit filter, h=5, k=4, "ACGTAC")
+    flt = bf.BloomFilter(1000000000, 5, 4)
+    hv, valid = bf.hash_seqs(b"ACGTAC", 5, 4)
+    pos, rows = emitted(hv, valid, 6, 4)
+    assert pos.tolist() == [0, 1, 2]
+    flt.insert(rows)
+    assert flt.contains(rows).all()
+    p = tmp_path / "u.bf"
+    flt.storeFilter(p)
+    raw = open(p, "rb").read()
+    i = raw.index(b"[HeaderEnd]\n") + 12
+    assert len(raw) - i == flt.sizeInBytes() == 125000000
+    f2 = bf.BloomFilter(path=p)
+    assert f2.contains(rows).all() and f2.getPop() == flt.getPop() <= 15
+
+
+def test_spaced_seed_filter(bf, oracle):
+    seeds = ["1110111011101110111011101110111", "1101101101101101011011011011011",
+             "1111001111001111111001111001111", "1011101011101011101011101011101"]
+    rng = np.random.RandomState(3)
+    s = rand_seq(rng, 20000, 0.002)
+    bits = 1 << 22
+    flt = bf.BloomFilter(bits, 4, 31)
+    flt.setSpacedSeeds(seeds, 1)
+    flt.insertSeqs(s)
+    pos, hv, st = oracle.sthash_seq(s, seeds, 1, 31)
+    mine = np.zeros(bits // 8, np.uint8)
+    oracle.bf_insert(mine, bits, 4, hv)
+    assert (flt.download() == mine).all()
+    hit, valid, cnt = flt.containsSeqs(s, want_counts=True)
+    assert cnt.tolist() == [len(pos), len(pos)]
+
+
+# ---------------------------------------------------------------------------------------------
+# counting filter
+# ---------------------------------------------------------------------------------------------
+def test_g4_counting_files(bf, tmp_path):
+    for f in load_golden("files.json"):
+        if f["kind"] != "counting":
+            continue
+        c = bf.CountingBloomFilter(f["bytes"], f["h"], f["k"], f["thr"])
+        assert c.size() == f["size"] == c.sizeInBytes()
+        for s in f["inserted"][:40]:
+            c.insertSeqs(s, increment_all=(f["op"] != "insert"), serial=True)
+        rest = f["inserted"][40:]
+        if rest:  # the saturation cases repeat one read 300 times: feed the rest as one ragged buffer
+            starts = np.cumsum([0] + [len(s) for s in rest]).astype(np.uint64)
+            c.insertSeqs("".join(rest).encode(), starts=starts, increment_all=(f["op"] != "insert"), serial=True)
+        p = tmp_path / f["file"]
+        c.storeFilter(p)
+        assert open(p, "rb").read() == open(os.path.join(GOLDEN, f["file"]), "rb").read(), f["file"]
+        assert c.popCount() == f["popcount"] and c.filtered_popcount() == f["filtered_popcount"]
+        c2 = bf.CountingBloomFilter(path=os.path.join(GOLDEN, f["file"]), countThreshold=f["thr"])
+        mins, hits = [], []
+        for s in f["inserted"]:
+            mn, valid = c2.minCountSeqs(s)
+            v = bf.bits_to_bool(valid, len(s))
+            mins += mn[v].tolist()
+            hit, _, _ = c2.containsSeqs(s)
+            hits += bf.bits_to_bool(hit, len(s))[v].astype(int).tolist()
+        assert mins == f["min_counts"] and hits == f["contains"]
+
+
+def test_counting_hash_rows_vs_oracle(bf, oracle):
+    rng = np.random.RandomState(5)
+    h, thr = 3, 2
+    c = bf.CountingBloomFilter(1001, h, 25, thr)
+    mine = np.zeros(1008, np.uint8)
+    for rnd in range(6):
+        hv = rng.randint(0, 2 ** 62, size=(700, h)).astype(np.uint64)
+        hv[::7, 1] = hv[::7, 0]
+        if rnd % 3 == 0:
+            c.incrementMin(hv, serial=True)
+            oracle.cbf_increment_min(mine, h, hv)
+        elif rnd % 3 == 1:
+            c.incrementAll(hv)  # parallel: saturating adds commute
+            oracle.cbf_increment_all(mine, h, hv)
+        else:
+            assert c.insertAndCheck(hv, serial=True).tolist() == oracle.cbf_insert_and_check(mine, h, thr, hv).tolist()
+        assert (c.download() == mine).all(), rnd
+        mn, ct = oracle.cbf_query(mine, h, thr, hv)
+        assert c.minCount(hv).tolist() == mn.tolist() and c.contains(hv).tolist() == ct.tolist()
+    assert c.popCount() == oracle.cbf_popcount(mine)
+    assert c.filtered_popcount() == oracle.cbf_filtered_popcount(mine, thr)
+
+
+def test_counting_parallel_increment_min_contract(bf, oracle):
+    # parallel incrementMin is not bit-reproducible (neither is the reference
+    # under OpenMP); it must stay <= incrementAll counters and never lose a k-mer inserted >= thr times
+    d = load_golden("digests.json")["cbf_small_all"]
+    reads = oracle.synth_reads(42, 0, 4000, 150)
+    cmin = bf.CountingBloomFilter(1 << 20, 3, 25, 2)
+    call = bf.CountingBloomFilter(1 << 20, 3, 25, 2)
+    for _ in range(2):
+        cmin.insertSeqs(reads, read_len=150)
+        call.insertSeqs(reads, read_len=150, increment_all=True)
+    a, b = cmin.download(), call.download()
+    assert (a <= b).all() and a.sum() > 0
+    hit, valid, cnt = cmin.containsSeqs(reads, read_len=150, want_counts=True)
+    assert cnt[0] == cnt[1] == 4000 * 126
+    # serial incrementMin is exact
+    ser = bf.CountingBloomFilter(1 << 20, 3, 25, 2)
+    mine = np.zeros(1 << 20, np.uint8)
+    ser.insertSeqs(reads[:150 * 300], read_len=150, serial=True)
+    for r in reads[:150 * 300].reshape(300, 150):
+        _, hv = oracle.nthash_seq(r.tobytes(), 3, 25)
+        oracle.cbf_increment_min(mine, 3, hv)
+    assert (ser.download() == mine).all()
+    assert d["op"] == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# G7: digests over synthetic reads (generated on the device)
+# ---------------------------------------------------------------------------------------------
+def test_synth_reads_device(bf, oracle):
+    d = load_golden("digests.json")["synth"]
+    r = bf.synth_reads_device(42, 0, 1000, 150).cpu().numpy()
+    assert r[:450].tobytes().decode() == d["first3"]
+    assert hashlib.sha256(r.tobytes()).hexdigest() == d["sha256_first_1000"]
+    assert hashlib.sha256(bf.synth_reads_device(43, 12345, 100, 150).cpu().numpy().tobytes()).hexdigest() == d["sha256_seed43_from_12345"]
+    assert hashlib.sha256(bf.synth_reads_device(7, 5, 64, 100).cpu().numpy().tobytes()).hexdigest() == d["sha256_len100"]
+
+
+@pytest.mark.parametrize("name", ["bf_small", "bf_nonpow2", "bf_medium", "bf_config1"])
+def test_g7_bloom_digests(bf, name):
+    import torch
+
+    g = load_golden("digests.json")[name]
+    flt = bf.BloomFilter(g["bits"], g["h"], g["k"])
+    step = 250000
+    for first in range(0, g["n_reads"], step):
+        n = min(step, g["n_reads"] - first)
+        reads = bf.synth_reads_device(g["seed"], first, n, g["read_len"])
+        flt.insertSeqs(reads, read_len=g["read_len"])
+    torch.cuda.synchronize()
+    assert flt.getPop() == g["pop"]
+    assert hashlib.sha256(flt.download().tobytes()).hexdigest() == g["body_sha256"]
+    for seed, key in ((42, "hits_seed42"), (43, "hits_seed43")):
+        q = bf.synth_reads_device(seed, 0, g["n_query"], g["read_len"])
+        _, _, cnt = flt.containsSeqs(q, read_len=g["read_len"], want_valid=False, want_counts=True)
+        torch.cuda.synchronize()
+        assert cnt.cpu().tolist() == [g["n_query"] * (g["read_len"] - g["k"] + 1), g[key]]
+
+
+@pytest.mark.parametrize("name", ["cbf_small_all", "cbf_medium_all", "cbf_small_min"])
+def test_g7_counting_digests(bf, name):
+    g = load_golden("digests.json")[name]
+    c = bf.CountingBloomFilter(g["bytes"], g["h"], g["k"], g["thr"])
+    for n in (g["n_reads"], g["n_reads"] // 2):
+        reads = bf.synth_reads_device(g["seed"], 0, n, g["read_len"])
+        c.insertSeqs(reads, read_len=g["read_len"], increment_all=(g["op"] == 1), serial=(g["op"] == 0))
+    assert c.popCount() == g["popcount"] and c.filtered_popcount() == g["filtered_popcount"]
+    assert hashlib.sha256(c.download().tobytes()).hexdigest() == g["body_sha256"]
+
+
+# ---------------------------------------------------------------------------------------------
+# size-independent properties at the BASELINE filter size (2^39 bits = 64 GiB)
+# ---------------------------------------------------------------------------------------------
+def test_full_size_filter_properties(bf):
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    bits = 1 << 39
+    if free < (bits // 8) + (8 << 30):
+        pytest.skip("not enough free HBM for a 64 GiB filter")
+    k, h, L, n = 31, 4, 150, 200000
+    flt = bf.BloomFilter(bits, h, k)
+    reads = bf.synth_reads_device(42, 0, n, L)
+    flt.insertSeqs(reads, read_len=L)
+    pop1 = flt.getPop()
+    # expected population = number of distinct positions, from the hash-only kernel + numpy
+    hv, valid = bf.hash_seqs(reads[: 20000 * L], h, k, read_len=L)
+    v = bf.bits_to_bool(valid.cpu().numpy().view(np.uint64), 20000 * L)
+    assert v.sum() == 20000 * 120
+    sub = bf.BloomFilter(bits, h, k)
+    sub.insertSeqs(reads[: 20000 * L], read_len=L)
+    pos = hv.cpu().numpy().view(np.uint64)[v] & np.uint64(bits - 1)
+    assert sub.getPop() == len(np.unique(pos))
+    # idempotence and no false negatives
+    flt.insertSeqs(reads, read_len=L)
+    assert flt.getPop() == pop1 and pop1 <= n * 120 * h
+    _, _, cnt = flt.containsSeqs(reads, read_len=L, want_valid=False, want_counts=True)
+    assert cnt.cpu().tolist() == [n * 120, n * 120]
+    q = bf.synth_reads_device(43, 0, n, L)
+    _, _, cnt = flt.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    assert cnt[0].item() == n * 120 and cnt[1].item() < 10
