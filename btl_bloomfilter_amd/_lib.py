@@ -78,6 +78,27 @@ _PROTOS = {
 EXPORTS = sorted(_PROTOS)
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's).  A process
+    must run ONE HIP runtime: whichever copy is loaded first wins, and torch cannot see the GPU through
+    the system copy.  So if torch is installed, load its copy before libbtlbf.so resolves the SONAME
+    (without importing torch); a later `import torch` then finds its own runtime already in place."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load(path=LIB_PATH):
     """Load libbtlbf.so (no GPU needed to load).  Raises if it has not been built."""
     global _lib
@@ -87,6 +108,7 @@ def load(path=LIB_PATH):
         raise ImportError(
             "%s not found: build it with `python -m btl_bloomfilter_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table disagree

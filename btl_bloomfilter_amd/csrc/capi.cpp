@@ -124,6 +124,10 @@ uint64_t srol_n(uint64_t x, unsigned s)
 }
 
 const uint64_t kSeeds[4] = {kSeedA, kSeedC, kSeedG, kSeedT};
+// forward / reverse-strand seed of a device base code (internal.hpp: codes 4..7 are raw bytes whose
+// "complement" under c & cpOff is the byte itself)
+uint64_t fwd_seed(unsigned c) { return kSeeds[c & 3]; }
+uint64_t rev_seed(unsigned c) { return c < 4 ? kSeeds[c ^ 3] : kSeeds[c & 3]; }
 
 void fill_hash_params(HashParams& hp, unsigned k, unsigned h)
 {
@@ -131,8 +135,8 @@ void fill_hash_params(HashParams& hp, unsigned k, unsigned h)
 	hp.k = k;
 	hp.h = h;
 	hp.kms = (uint64_t)k * kMultiSeed;
-	for (int c = 0; c < 4; ++c) {
-		const uint64_t s = kSeeds[c], rc = kSeeds[c ^ 3];
+	for (unsigned c = 0; c < kNumCodes; ++c) {
+		const uint64_t s = fwd_seed(c), rc = rev_seed(c);
 		hp.init_tab[c][0] = s;
 		hp.init_tab[c][1] = srol_n(rc, k - 1);
 		hp.in_tab[c][0] = s;
@@ -163,11 +167,11 @@ int build_spaced(HashParams& hp, const char* const* seeds, unsigned n_seeds, uns
 				dc.push_back((uint16_t)i);
 	}
 	hp.dc_off[n_seeds] = (uint32_t)dc.size();
-	std::vector<uint64_t> pos((size_t)k * 8);
+	std::vector<uint64_t> pos((size_t)k * kNumCodes * 2);
 	for (unsigned i = 0; i < k; ++i)
-		for (int c = 0; c < 4; ++c) {
-			pos[((size_t)i * 4 + c) * 2 + 0] = srol_n(kSeeds[c], k - 1 - i);
-			pos[((size_t)i * 4 + c) * 2 + 1] = srol_n(kSeeds[c ^ 3], i);
+		for (unsigned c = 0; c < kNumCodes; ++c) {
+			pos[((size_t)i * kNumCodes + c) * 2 + 0] = srol_n(fwd_seed(c), k - 1 - i);
+			pos[((size_t)i * kNumCodes + c) * 2 + 1] = srol_n(rev_seed(c), i);
 		}
 	HIP_TRY(hipMalloc((void**)d_pos, pos.size() * 8));
 	HIP_TRY(hipMemcpy(*d_pos, pos.data(), pos.size() * 8, hipMemcpyHostToDevice));
@@ -354,7 +358,7 @@ int make_filter(btlbf_filter** out, int kind, uint64_t size, uint64_t size_bytes
 	if (size < 8)
 		return fail(BTLBF_EINVAL, "filter size %llu too small", (unsigned long long)size);
 	if (shard_count == 0 || shard_index >= shard_count || size % shard_count ||
-	    (size / shard_count) % 64)
+	    (shard_count > 1 && (size / shard_count) % 64))
 		return fail(BTLBF_EINVAL, "shard %u of %u does not split %llu positions into multiples of 64",
 		            shard_index, shard_count, (unsigned long long)size);
 	if (btlbf_device_count() <= device || device < 0)

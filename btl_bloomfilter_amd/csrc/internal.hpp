@@ -14,10 +14,15 @@ static constexpr uint64_t kSeedT = 0x295549f54be24456ULL;
 static constexpr uint64_t kMultiSeed = 0x90b45d39fb6da1faULL;
 static constexpr unsigned kMultiShift = 27;
 
-// base codes used on the device: A=0 C=1 G=2 T=3, complement = code ^ 3
-// per-base byte staged in LDS: bits 1:0 code, bit 2 = valid base, bit 3 = first base of a sequence
-static constexpr unsigned kBaseValid = 4u;
-static constexpr unsigned kBaseStart = 8u;
+// base codes used on the device: A=0 C=1 G=2 T=3 with reverse-strand seed = seed[code ^ 3]; codes
+// 4..7 are the raw bytes {4,5} 7 3 1 that the reference's seedTab also accepts
+// (vendor/nthash.hpp:196): their forward seed is A C G T and -- because "c & cpOff" maps such a
+// byte to itself (nthash.hpp:180,688) -- their reverse-strand seed is the SAME seed.
+// per-base byte staged in LDS: bits 2:0 code, bit 3 = valid base, bit 4 = first base of a sequence
+static constexpr unsigned kCodeMask = 7u;
+static constexpr unsigned kNumCodes = 8u;
+static constexpr unsigned kBaseValid = 8u;
+static constexpr unsigned kBaseStart = 16u;
 
 static constexpr int kMaxHash = 32;  // hash_num supported by the fused kernels
 static constexpr int kMaxSeeds = 16; // spaced seeds per filter
@@ -40,14 +45,14 @@ struct HashParams {
 	uint32_t n_seeds;  // 0 = plain ntHash (ntHashIterator); >0 = spaced seeds (stHashIterator)
 	uint32_t h2;
 	uint64_t kms;      // k * multiSeed (nthash.hpp:585-589: multiplier is i ^ (k*multiSeed))
-	// per code c: {seed[c], srol^(k-1)(seed[c^3])}            -> Horner start-up of fh / rh
-	uint64_t init_tab[4][2];
-	// per code c: {seed[c], srol^k(seed[c^3])}                -> roll, incoming base
-	uint64_t in_tab[4][2];
-	// per code c: {srol^k(seed[c]), seed[c^3]}                -> roll, outgoing base
-	uint64_t out_tab[4][2];
+	// per code c: {fwd[c], srol^(k-1)(rev[c])}                 -> Horner start-up of fh / rh
+	uint64_t init_tab[8][2];
+	// per code c: {fwd[c], srol^k(rev[c])}                    -> roll, incoming base
+	uint64_t in_tab[8][2];
+	// per code c: {srol^k(fwd[c]), rev[c]}                    -> roll, outgoing base
+	uint64_t out_tab[8][2];
 	// spaced seeds (device memory, owned by the filter / call):
-	//   pos_tab[i*4+c] = {srol^(k-1-i)(seed[c]), srol^i(seed[c^3])}, i<k
+	//   pos_tab[i*8+c] = {srol^(k-1-i)(fwd seed of c), srol^i(reverse seed of c)}, i<k
 	//   dc_idx = concatenated don't-care indices, seed j uses [dc_off[j], dc_off[j+1])
 	const uint64_t* pos_tab;
 	const uint16_t* dc_idx;

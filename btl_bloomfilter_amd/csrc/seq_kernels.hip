@@ -3,7 +3,7 @@
 // One launch walks a sequence buffer of `len` bytes.  A workgroup (256 threads = 4 wavefronts)
 // owns a contiguous run of tiles; a tile is kTile = 2048 consecutive window start offsets.
 //   1. stage: coalesced 16-byte loads of the tile's kTile+k-1 bytes; each byte goes through a
-//      256-entry LDS table to a 2-bit base code + "valid base" flag and is written back to LDS;
+//      256-entry LDS table to a 2-bit base code (3 bits with the raw-byte aliases) + "valid base" flag and is written back to LDS;
 //      sequence starts inside the tile get a "start" flag (read_len arithmetic or the starts[] array).
 //   2. hash: each lane owns kW = 8 consecutive windows: Horner start-up of the forward and reverse
 //      hashes over the first window (k LDS reads), then 7 O(1) rolls.  A window is clean iff its
@@ -34,9 +34,9 @@ struct __attribute__((aligned(16))) U64x2 {
 
 // static LDS: translation table + hash tables
 struct SeqShared {
-	U64x2 init_tab[4];
-	U64x2 in_tab[4];
-	U64x2 out_tab[4];
+	U64x2 init_tab[kNumCodes];
+	U64x2 in_tab[kNumCodes];
+	U64x2 out_tab[kNumCodes];
 	uint8_t lut[256];
 	unsigned long long cnt_valid;
 	unsigned long long cnt_hit;
@@ -49,10 +49,14 @@ struct SeqShared {
 __device__ __forceinline__ uint8_t base_entry(uint32_t c)
 {
 	switch (c) {
-	case 'A': case 'a': case 4: case 5: return 0 | kBaseValid;
-	case 'C': case 'c': case 7:         return 1 | kBaseValid;
-	case 'G': case 'g': case 3:         return 2 | kBaseValid;
-	case 'T': case 't': case 'U': case 'u': case 1: return 3 | kBaseValid;
+	case 'A': case 'a': return 0 | kBaseValid;
+	case 'C': case 'c': return 1 | kBaseValid;
+	case 'G': case 'g': return 2 | kBaseValid;
+	case 'T': case 't': case 'U': case 'u': return 3 | kBaseValid;
+	case 4: case 5: return 4 | kBaseValid; // raw bytes: forward A C G T, reverse seed = forward seed
+	case 7: return 5 | kBaseValid;
+	case 3: return 6 | kBaseValid;
+	case 1: return 7 | kBaseValid;
 	default: return 0;
 	}
 }
@@ -70,11 +74,11 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 	const uint32_t tile_cap = ((kTile + k - 1 + 15 + 15) / 16) * 16; // + up to 15 bytes of misalignment
 	uint8_t* tile = dyn;
 	const U64x2* pos_tab = reinterpret_cast<const U64x2*>(dyn + tile_cap);
-	const uint16_t* dc_idx = reinterpret_cast<const uint16_t*>(dyn + tile_cap + (SPACED ? k * 4 * 16 : 0));
+	const uint16_t* dc_idx = reinterpret_cast<const uint16_t*>(dyn + tile_cap + (SPACED ? k * kNumCodes * 16 : 0));
 
 	// ---- one-time table setup ----
 	sh.lut[tid] = base_entry(tid);
-	if (tid < 4) {
+	if (tid < kNumCodes) {
 		sh.init_tab[tid] = U64x2{a.hp.init_tab[tid][0], a.hp.init_tab[tid][1]};
 		sh.in_tab[tid] = U64x2{a.hp.in_tab[tid][0], a.hp.in_tab[tid][1]};
 		sh.out_tab[tid] = U64x2{a.hp.out_tab[tid][0], a.hp.out_tab[tid][1]};
@@ -85,9 +89,9 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 	}
 	if (SPACED) {
 		uint64_t* pt = reinterpret_cast<uint64_t*>(dyn + tile_cap);
-		for (uint32_t i = tid; i < k * 8; i += kThreads)
+		for (uint32_t i = tid; i < k * kNumCodes * 2; i += kThreads)
 			pt[i] = a.hp.pos_tab[i];
-		uint16_t* di = reinterpret_cast<uint16_t*>(dyn + tile_cap + k * 4 * 16);
+		uint16_t* di = reinterpret_cast<uint16_t*>(dyn + tile_cap + k * kNumCodes * 16);
 		const uint32_t ndc = a.hp.dc_off[a.hp.n_seeds];
 		for (uint32_t i = tid; i < ndc; i += kThreads)
 			di[i] = a.hp.dc_idx[i];
@@ -186,13 +190,13 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 		uint32_t first_valid;
 		{
 			uint32_t e = tile[li0];
-			first_valid = (e >> 2) & 1;
-			U64x2 tt = sh.init_tab[e & 3];
+			first_valid = (e >> 3) & 1;
+			U64x2 tt = sh.init_tab[e & kCodeMask];
 			fh = tt.x;
 			rh = tt.y;
 			for (uint32_t i = 1; i < k; ++i) {
 				e = tile[li0 + i];
-				tt = sh.init_tab[e & 3];
+				tt = sh.init_tab[e & kCodeMask];
 				fh = srol1(fh) ^ tt.x;
 				rh = sror1(rh) ^ tt.y;
 				cnt += ((e & (kBaseValid | kBaseStart)) == kBaseValid);
@@ -215,13 +219,13 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 				const uint32_t eo = tile[li0 + w - 1];
 				const uint32_t ei = tile[li0 + w - 1 + k];
 				const uint32_t en = tile[li0 + w];
-				const U64x2 ti = sh.in_tab[ei & 3];
-				const U64x2 to = sh.out_tab[eo & 3];
+				const U64x2 ti = sh.in_tab[ei & kCodeMask];
+				const U64x2 to = sh.out_tab[eo & kCodeMask];
 				fh = srol1(fh) ^ ti.x ^ to.x;
 				rh = sror1(rh ^ ti.y ^ to.y);
 				cnt += ((ei & (kBaseValid | kBaseStart)) == kBaseValid);
 				cnt -= ((en & (kBaseValid | kBaseStart)) == kBaseValid);
-				first_valid = (en >> 2) & 1;
+				first_valid = (en >> 3) & 1;
 			}
 			const bool ok = first_valid && cnt == k - 1;
 			valid_mask |= (uint32_t)ok << w;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 					uint64_t fs = fh, rs = rh;
 					for (uint32_t d = a.hp.dc_off[j]; d < a.hp.dc_off[j + 1]; ++d) {
 						const uint32_t i = dc_idx[d];
-						const U64x2 tt = pos_tab[i * 4 + (tile[li0 + w + i] & 3)];
+						const U64x2 tt = pos_tab[i * kNumCodes + (tile[li0 + w + i] & kCodeMask)];
 						fs ^= tt.x;
 						rs ^= tt.y;
 					}
@@ -456,7 +460,7 @@ hipError_t launch_seq_op(int op, const SeqArgs& a_in, hipStream_t s)
 	const uint32_t k = a.hp.k;
 	size_t dyn = ((kTile + k - 1 + 15 + 15) / 16) * 16;
 	if (a.hp.n_seeds > 0)
-		dyn += (size_t)k * 4 * 16 + (((size_t)a.hp.dc_off[a.hp.n_seeds] * 2 + 15) / 16) * 16;
+		dyn += (size_t)k * kNumCodes * 16 + (((size_t)a.hp.dc_off[a.hp.n_seeds] * 2 + 15) / 16) * 16;
 	dim3 grid((unsigned)blocks);
 	switch (op) {
 	case OP_BF_INSERT: return launch_one<OP_BF_INSERT>(a, s, grid, dyn);

@@ -88,15 +88,16 @@ class _Filter:
     def _create(cls, size, hash_num, kmer_size, threshold=0, device=0):
         L = _lib.load()
         h = C.c_void_p()
-        check(L.btlbf_create(C.byref(h), cls.kind, size, hash_num, kmer_size, threshold, device))
-        return cls(h)
+        check(L.btlbf_create(C.byref(h), cls.kind, int(size), int(hash_num), int(kmer_size), int(threshold),
+                             int(device)))
+        return h
 
     @classmethod
     def _load(cls, path, threshold=0, device=0):
         L = _lib.load()
         h = C.c_void_p()
-        check(L.btlbf_load(C.byref(h), cls.kind, str(path).encode(), threshold, device))
-        return cls(h)
+        check(L.btlbf_load(C.byref(h), cls.kind, str(path).encode(), int(threshold), int(device)))
+        return h
 
     def close(self):
         if getattr(self, "_h", None):
@@ -216,13 +217,9 @@ class BloomFilter(_Filter):
         if _handle is not None:
             super().__init__(_handle)
         elif path is not None:
-            super().__init__(type(self)._load(path, 0, device)._steal())
+            super().__init__(self._load(path, 0, device))
         else:
-            super().__init__(type(self)._create(filterSize, hashNum, kmerSize, 0, device)._steal())
-
-    def _steal(self):
-        h, self._h = self._h, None
-        return h
+            super().__init__(self._create(filterSize, hashNum, kmerSize, 0, device))
 
     @classmethod
     def shard(cls, global_bits, shard_index, shard_count, hashNum, kmerSize, device=0):
@@ -289,11 +286,9 @@ class CountingBloomFilter(_Filter):
 
     def __init__(self, sizeInBytes=None, hashNum=None, kmerSize=None, countThreshold=0, path=None, device=0):
         if path is not None:
-            t = type(self)._load(path, countThreshold, device)
+            super().__init__(self._load(path, countThreshold, device))
         else:
-            t = type(self)._create(sizeInBytes, hashNum, kmerSize, countThreshold, device)
-        h, t._h = t._h, None
-        super().__init__(h)
+            super().__init__(self._create(sizeInBytes, hashNum, kmerSize, countThreshold, device))
 
     def size(self):
         return self._L.btlbf_size(self._h)

@@ -1,0 +1,39 @@
+"""Quick timing of the fused insert / contains kernels on synthetic reads (not the contract bench)."""
+import json
+import sys
+import time
+
+import torch
+
+import btl_bloomfilter_amd as m
+
+
+def main():
+    lg = int(sys.argv[1]) if len(sys.argv) > 1 else 39
+    n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+    k, h, L = 31, 4, 150
+    f = m.BloomFilter(1 << lg, h, k)
+    reads = m.synth_reads_device(42, 0, n_reads, L)
+    q = m.synth_reads_device(43, 0, n_reads, L)
+    torch.cuda.synchronize()
+    kmers = n_reads * (L - k + 1)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    st = torch.cuda.current_stream()
+    for rep in range(3):
+        f.clear(stream=st)
+        ev[0].record()
+        f.insertSeqs(reads, read_len=L, stream=st)
+        ev[1].record()
+        _, _, c1 = f.containsSeqs(reads, read_len=L, want_valid=False, want_counts=True, stream=st)
+        ev[2].record()
+        _, _, c2 = f.containsSeqs(q, read_len=L, want_valid=False, want_counts=True, stream=st)
+        ev[3].record()
+        torch.cuda.synchronize()
+        ti, th, tm = ev[0].elapsed_time(ev[1]) / 1e3, ev[1].elapsed_time(ev[2]) / 1e3, ev[2].elapsed_time(ev[3]) / 1e3
+        print(json.dumps({"log2_bits": lg, "reads": n_reads, "insert_Gkmers_s": kmers / ti / 1e9,
+                          "query_hit_Gkmers_s": kmers / th / 1e9, "query_miss_Gkmers_s": kmers / tm / 1e9,
+                          "hits": c1.tolist(), "miss": c2.tolist()}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
