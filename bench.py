@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's benchmark contract for the k-mer Bloom filter hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], "C2"): per GPU a 2^39-bit (64 GiB) BloomFilter, k=31, h=4, and
+100 M synthetic 150 bp reads (SURVEY.md 8d generator, seed 42) resident in HBM before timing starts.
+One step = clear the filter, insert all reads (fused ntHash + atomicOr kernel), query all reads
+(fused ntHash + gather kernel; every k-mer is a hit, the per-k-mer contains() bitmask is written).
+value = (k-mers inserted + k-mers queried) / wall time, whole job.
+
+N > 1 (weak scaling): the filter is N x 64 GiB, hash-range sharded over the ranks
+(btl_bloomfilter_amd/sharded.py): every rank hashes its own 100 M reads, routes probe positions to
+the owning shard with an RCCL all-to-all, and (query) routes the answers back.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (the insert kernel), measured with
+HIP events on the launch stream; "roofline_query" likewise; "cpu_baseline" = the genuine reference
+build (oracle/_ref, kind "reference") or the C port (oracle/, kind "port") timed on this box's host
+cores over a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+K, H, READ_LEN = 31, 4, 150
+LOG2_BITS = 39
+N_READS = 100_000_000
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic bytes per k-mer, SURVEY.md 8d: query h*64 + L/(L-k+1); insert h*128 + L/(L-k+1)
+BYTES_QUERY = H * 64 + READ_LEN / (READ_LEN - K + 1)
+BYTES_INSERT = H * 128 + READ_LEN / (READ_LEN - K + 1)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BTLBF_BENCH_READS", N_READS)),
+                    help="reads per GPU (default: the C2 workload, 100 M)")
+    ap.add_argument("--log2-bits", type=int, default=int(os.environ.get("BTLBF_BENCH_LOG2_BITS", LOG2_BITS)),
+                    help="log2 of filter bits per GPU (default 39 = 64 GiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reads", type=int, default=2_000_000)
+    return ap.parse_args()
+
+
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def host_cores():
+    """cores this process may really use: the affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(n_reads, log2_bits):
+    """Reference CPU path (ntHashIterator + BloomFilter insert/contains, OpenMP over reads) on a
+    bounded sample; falls back to the C port when the reference build is not on this machine."""
+    from oracle import pyoracle
+
+    cores = host_cores()
+    avail = mem_available_bytes()
+    lg = log2_bits
+    while lg > 30 and (1 << lg) // 8 > 0.55 * avail:
+        lg -= 1
+    bits = 1 << lg
+    if pyoracle.Ref.available():
+        kind, runner = "reference", pyoracle.Ref()
+    else:
+        pyoracle.build()
+        kind, runner = "port", pyoracle.Oracle()
+    t0 = time.time()
+    r = runner.bench_bf(n_reads, READ_LEN, K, H, bits, 42, 42, threads=cores, prefault=1)
+    wall = time.time() - t0
+    kmers = r["kmers"]
+    val = 2 * kmers / (r["t_insert"] + r["t_query"]) / 1e6
+    return {
+        "value": val, "unit": "Mk-mers/s", "cores": r["threads"], "kind": kind,
+        "insert_Mkmers_s": kmers / r["t_insert"] / 1e6, "query_Mkmers_s": kmers / r["t_query"] / 1e6,
+        "sample": "%d synthetic 150 bp reads (seed 42) inserted then queried (all hits), k=31 h=4, "
+                  "2^%d-bit filter (%s), pages pre-touched, OpenMP over reads, %.0f s wall incl. prefault"
+                  % (n_reads, lg, "same size as the GPU run" if lg == log2_bits else "scaled to host RAM", wall),
+        "query_hits": r["hits"], "kmers": kmers,
+    }
+
+
+def load_traffic():
+    """per-launch HBM bytes from the rocprofv3 PMC runs committed under profiles/ (or None)"""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except ValueError:
+            return None
+    return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+
+    import btl_bloomfilter_amd as m
+    from btl_bloomfilter_amd import _lib
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = _lib.load()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_reads = args.reads
+    bits_per_gpu = 1 << args.log2_bits
+    kmers = n_reads * (READ_LEN - K + 1)
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+
+    # ---- resident inputs: synthetic reads of this rank (rank r owns reads [r*n, (r+1)*n)) ----
+    reads = m.synth_reads_device(42, rank * n_reads, n_reads, READ_LEN, device=local_rank)
+    lay = _lib.Layout()
+    lay.starts, lay.n_seqs, lay.read_len = None, 0, READ_LEN
+    n_bytes = reads.numel()
+    hit_bits = torch.zeros((n_bytes + 63) // 64, dtype=torch.int64, device=dev)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    if world == 1:
+        flt = m.BloomFilter(bits_per_gpu, H, K, device=local_rank)
+
+        def do_insert():
+            _lib.check(lib.btlbf_insert_seqs(flt._h, C.c_void_p(reads.data_ptr()), n_bytes, C.byref(lay), 0, 0,
+                                             _lib.DEVICE, sp))
+
+        def do_query():
+            _lib.check(lib.btlbf_contains_seqs(flt._h, C.c_void_p(reads.data_ptr()), n_bytes, C.byref(lay),
+                                               C.c_void_p(hit_bits.data_ptr()), None,
+                                               C.c_void_p(counts.data_ptr()), _lib.DEVICE, sp))
+
+        def do_clear():
+            _lib.check(lib.btlbf_clear(flt._h, sp))
+    else:
+        from btl_bloomfilter_amd.sharded import ShardedBloomFilter
+
+        flt = ShardedBloomFilter(bits_per_gpu * world, H, K, device=local_rank)
+
+        def do_insert():
+            flt.insert_reads(reads, READ_LEN)
+
+        def do_query():
+            flt.contains_reads(reads, READ_LEN, hit_bits, counts)
+
+        def do_clear():
+            flt.clear()
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    t_ins, t_qry = [], []
+
+    def step(timed):
+        e = [ev() for _ in range(4)]
+        do_clear()
+        e[0].record(stream)
+        do_insert()
+        e[1].record(stream)
+        e[2].record(stream)
+        do_query()
+        e[3].record(stream)
+        return e if timed else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    events = [step(True) for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    for e in events:
+        t_ins.append(e[0].elapsed_time(e[1]) * 1e-3)
+        t_qry.append(e[2].elapsed_time(e[3]) * 1e-3)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = counts.clone()
+        dist.all_reduce(c)
+        tot_counts = c.tolist()
+    else:
+        tot_counts = counts.tolist()
+
+    if rank == 0:
+        total_kmers = kmers * world
+        assert tot_counts[0] == total_kmers, "query saw %d clean k-mers, expected %d" % (tot_counts[0], total_kmers)
+        assert tot_counts[1] == total_kmers, "false negatives: %d hits of %d" % (tot_counts[1], total_kmers)
+        value = 2 * total_kmers * args.steps / elapsed / 1e6
+        ins = sum(t_ins) / len(t_ins)
+        qry = sum(t_qry) / len(t_qry)
+        traffic = load_traffic() or {}
+        out = {
+            "metric": "Mk-mers/s insert+query, k=31 h=4, 64 GiB filter",
+            "value": value, "unit": "Mk-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "C2: per GPU 2^%d-bit BloomFilter, k=31, h=4, %d synthetic 150 bp reads "
+                                   "inserted then queried (all hits), reads resident in HBM"
+                                   % (args.log2_bits, n_reads),
+                       "filter_bits_total": bits_per_gpu * world, "kmers_per_pass": total_kmers,
+                       "parallelism": "1 GPU" if world == 1 else "hash-range shards x%d, RCCL all-to-all" % world},
+            "insert_Mkmers_s": total_kmers / ins / 1e6, "query_Mkmers_s": total_kmers / qry / 1e6,
+        }
+        if world == 1:
+            a_ins = kmers * BYTES_INSERT / ins / 1e9
+            a_qry = kmers * BYTES_QUERY / qry / 1e9
+            out["roofline"] = {"kernel": "seq_kernel<OP_BF_INSERT> (fused ntHash + atomicOr)", "bound": "hbm",
+                               "achieved": a_ins, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_ins / HBM_PEAK_GBS,
+                               "traffic": traffic.get("insert_bytes_per_launch"),
+                               "bytes_per_kmer": BYTES_INSERT, "kmers_per_launch": kmers, "launch_ms": ins * 1e3}
+            out["roofline_query"] = {"kernel": "seq_kernel<OP_BF_CONTAINS> (fused ntHash + gather)", "bound": "hbm",
+                                     "achieved": a_qry, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": a_qry / HBM_PEAK_GBS,
+                                     "traffic": traffic.get("query_bytes_per_launch"),
+                                     "bytes_per_kmer": BYTES_QUERY, "kmers_per_launch": kmers,
+                                     "launch_ms": qry * 1e3}
+            if not args.no_cpu_baseline:
+                del reads, hit_bits
+                try:
+                    out["cpu_baseline"] = cpu_baseline(args.cpu_reads, args.log2_bits)
+                except Exception as exc:  # the baseline is a report, never a reason to lose the bench line
+                    out["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
