@@ -68,7 +68,9 @@ _PROTOS = {
                                   C.POINTER(Layout), _P, _P, _P, C.c_int, C.c_int, _P]),
     "btlbf_popcount": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "btlbf_filtered_popcount": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
-    "btlbf_positions_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_uint, _P, _P, C.c_uint64, _P, _P]),
+    "btlbf_positions_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_uint, _P, _P, C.c_uint64, _P, _P,
+                                       _P]),
+    "btlbf_popcount_bits": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64), C.c_int, _P]),
     "btlbf_insert_positions": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "btlbf_test_positions": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     "btlbf_and_answers": (C.c_int, [_P, _P, C.c_uint64, C.c_uint, _P, C.c_int, _P]),

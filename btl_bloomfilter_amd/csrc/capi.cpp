@@ -1078,7 +1078,7 @@ extern "C" int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out)
 extern "C" int btlbf_positions_seqs(btlbf_filter* f, const char* seq, uint64_t len,
                                     const btlbf_layout* layout, unsigned n_shards, uint64_t* buckets,
                                     uint64_t* tags, uint64_t bucket_cap, uint64_t* bucket_counts,
-                                    void* stream)
+                                    uint64_t* valid_bits, void* stream)
 {
 	int rc = seq_precheck(f, len);
 	if (rc)
@@ -1100,6 +1100,7 @@ extern "C" int btlbf_positions_seqs(btlbf_filter* f, const char* seq, uint64_t l
 	a.tags = tags;
 	a.bucket_cap = bucket_cap;
 	a.bucket_counts = reinterpret_cast<unsigned long long*>(bucket_counts);
+	a.valid_bits = reinterpret_cast<uint8_t*>(valid_bits);
 	HIP_TRY(hipMemsetAsync(bucket_counts, 0, (size_t)n_shards * 8, s));
 	HIP_TRY(launch_seq_op(OP_POSITIONS, a, s));
 	return BTLBF_OK;
@@ -1135,6 +1136,26 @@ extern "C" int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, u
 		return fail(BTLBF_EINVAL, "null argument");
 	DeviceGuard g(device);
 	HIP_TRY(launch_and_answers(tags, answers, n, hash_num, hit_bits, static_cast<hipStream_t>(stream)));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_popcount_bits(const void* dev_buf, uint64_t nbytes, uint64_t* out, int device,
+                                   void* stream)
+{
+	if (!out || (nbytes && !dev_buf))
+		return fail(BTLBF_EINVAL, "null argument");
+	if (nbytes % 16)
+		return fail(BTLBF_EINVAL, "nbytes must be a multiple of 16");
+	DeviceGuard g(device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	DevBuf acc;
+	HIP_TRY(acc.alloc(8));
+	HIP_TRY(hipMemsetAsync(acc.p, 0, 8, s));
+	HIP_TRY(launch_popcount(dev_buf, nbytes, 0, 0, acc.as<unsigned long long>(), s));
+	unsigned long long v = 0;
+	HIP_TRY(hipMemcpyAsync(&v, acc.p, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	*out = v;
 	return BTLBF_OK;
 }
 

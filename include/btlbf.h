@@ -173,24 +173,30 @@ int btlbf_popcount(btlbf_filter* f, uint64_t* out);
 int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out);
 
 /* ---- multi-GPU hash-range sharding ------------------------------------------------
- * positions_seqs: hash the buffer and, instead of probing, append each probe's filter position to
- * the bucket of its owning shard.  buckets = n_shards regions of `bucket_cap` uint64_t each in one
- * device array; bucket_counts[n_shards] (device, zeroed by the call) receives the fill.  Entry =
- * position local to the owning shard, with (window_id << 40 | probe slot...) NOT encoded: for
- * queries the parallel array `tags` (same shape, may be NULL) receives the probe id
- * (window offset p * hash_num + i) so that answers can be routed back.
- * insert_positions / test_positions act on local positions of this shard. */
+ * The M-bit filter is cut into n_shards contiguous bit ranges; shard g (btlbf_create_shard) holds
+ * positions [g*M/n, (g+1)*M/n).  Routing is by POSITION, so the concatenated shard bodies are the
+ * single-filter body bit for bit.
+ * positions_seqs: hash a device-resident sequence buffer with f's parameters and, instead of probing,
+ *   append every probe of every clean window to the bucket of the shard that owns its position.
+ *   buckets = n_shards regions of bucket_cap uint64_t in one device array; an entry is the position
+ *   LOCAL to the owning shard.  tags (same shape, may be NULL) receives the probe id p*hash_num + i
+ *   (p = window offset) so that routed answers can be matched up again.  bucket_counts[n_shards]
+ *   (device) is zeroed by the call and receives the fill; a count above bucket_cap means entries
+ *   were dropped and the caller must retry with a larger capacity.  valid_bits (device, may be
+ *   NULL) is the usual per-window bitmap.
+ * insert_positions / test_positions act on local positions of this shard (test: one byte 0/1 each).
+ * and_answers: origin side of a sharded query -- answers[i] belongs to probe tags[i]; a 0 answer
+ *   clears the bit of window tags[i]/hash_num in hit_bits (which starts as a copy of valid_bits). */
 int btlbf_positions_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
                          unsigned n_shards, uint64_t* buckets, uint64_t* tags, uint64_t bucket_cap,
-                         uint64_t* bucket_counts, void* stream);
+                         uint64_t* bucket_counts, uint64_t* valid_bits, void* stream);
 int btlbf_insert_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n, void* stream);
-/* out_bits: one byte per position (0/1) */
 int btlbf_test_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n, uint8_t* out,
                          void* stream);
-/* origin side of a sharded query: AND the returned probe answers into per-window results.
- * answers[i] belongs to probe tags[i]; hit_bits must have been initialised with the valid bits. */
 int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, unsigned hash_num,
                       uint64_t* hit_bits, int device, void* stream);
+/* number of set bits in a device buffer (e.g. a hit bitmap); synchronises the stream */
+int btlbf_popcount_bits(const void* dev_buf, uint64_t nbytes, uint64_t* out, int device, void* stream);
 
 /* ---- support ------------------------------------------------------------------------------------
  * synthetic reads of SURVEY.md 8d written to device memory: n reads x read_len bytes */

@@ -1,0 +1,211 @@
+// include/btlbf/BloomFilter.hpp -- drop-in for the reference's `BloomFilter` class
+// (/root/reference/BloomFilter.hpp:40-446) whose bit array lives in MI355X HBM.
+//
+// Same class name, constructors and method names as the reference; every call forwards to the C
+// ABI (include/btlbf.h), i.e. to the HIP kernels -- nothing is computed on the host.
+//   * insert(hashes) is write-combined: rows are queued on the host and pushed to the GPU in one
+//     btlbf_insert_hashes call when the queue fills or before anything reads the filter.  Bit OR is
+//     order-free, so this is invisible to callers (reference: BloomFilter.hpp:171-194).
+//   * contains()/insertAndCheck() per k-mer cost one GPU round trip each; use the *Seq/*Seqs batch
+//     members (or BloomFilterUtil.h's insertSeq) on the fast path.
+//   * not reproduced on purpose: the (expectedElemNum, fpr, ...) constructor, which in the reference
+//     deletes an uninitialised pointer (BloomFilter.hpp:83-99 vs :396-397).
+#ifndef BTLBF_BLOOMFILTER_HPP
+#define BTLBF_BLOOMFILTER_HPP
+#include "detail.hpp"
+
+#include <cmath>
+#include <fstream>
+#include <string>
+#include <vector>
+
+class BloomFilter
+{
+  public:
+	BloomFilter() = default;
+
+	// BloomFilter(size_t filterSize, unsigned hashNum, unsigned kmerSize), BloomFilter.hpp:65-76
+	BloomFilter(size_t filterSize, unsigned hashNum, unsigned kmerSize)
+	{
+		btlbf_shim::check(btlbf_create(&m_f, BTLBF_BLOOM, filterSize, hashNum, kmerSize, 0,
+		                               btlbf_shim::default_device()));
+	}
+
+	// BloomFilter(const string& filterFilePath), BloomFilter.hpp:101-105
+	explicit BloomFilter(const std::string& filterFilePath) { loadFilter(filterFilePath); }
+
+	virtual ~BloomFilter() { btlbf_destroy(m_f); }
+
+	void loadFilter(const std::string& filterFilePath) // BloomFilter.hpp:107-116
+	{
+		btlbf_destroy(m_f);
+		m_f = nullptr;
+		m_pending.clear();
+		btlbf_shim::check(
+		    btlbf_load(&m_f, BTLBF_BLOOM, filterFilePath.c_str(), 0, btlbf_shim::default_device()));
+	}
+
+	// ---- per-k-mer interface (precomputed hash values, m_hashNum per k-mer) ----
+	void insert(const uint64_t precomputed[]) // BloomFilter.hpp:185-194
+	{
+		const unsigned h = getHashNum();
+		m_pending.insert(m_pending.end(), precomputed, precomputed + h);
+		if (m_pending.size() >= kFlushRows * (size_t)h)
+			flush();
+	}
+	void insert(std::vector<uint64_t> const& precomputed) // BloomFilter.hpp:171-180 (.at() range check)
+	{
+		(void)precomputed.at(getHashNum() - 1);
+		insert(precomputed.data());
+	}
+
+	bool insertAndCheck(const uint64_t precomputed[]) // BloomFilter.hpp:200-214
+	{
+		flush();
+		uint8_t out = 0;
+		btlbf_shim::check(btlbf_insert_and_check_hashes(m_f, precomputed, 1, &out, BTLBF_ORDER_SERIAL,
+		                                                BTLBF_HOST, nullptr));
+		return out != 0;
+	}
+	bool insertAndCheck(std::vector<uint64_t> const& precomputed) // BloomFilter.hpp:220-232
+	{
+		(void)precomputed.at(getHashNum() - 1);
+		return insertAndCheck(precomputed.data());
+	}
+
+	bool contains(const uint64_t precomputed[]) const // BloomFilter.hpp:252-262
+	{
+		flush();
+		uint8_t out = 0;
+		btlbf_shim::check(btlbf_contains_hashes(m_f, precomputed, 1, &out, BTLBF_HOST, nullptr));
+		return out != 0;
+	}
+	bool contains(std::vector<uint64_t> const& precomputed) const // BloomFilter.hpp:237-247
+	{
+		(void)precomputed.at(getHashNum() - 1);
+		return contains(precomputed.data());
+	}
+
+	// ---- batch interface (the fast path; no counterpart in the reference) ----
+	// n rows of m_hashNum hashes each
+	void insertBatch(const uint64_t* rows, size_t n)
+	{
+		flush();
+		btlbf_shim::check(btlbf_insert_hashes(m_f, rows, n, 0, BTLBF_ORDER_PARALLEL, BTLBF_HOST, nullptr));
+	}
+	std::vector<uint8_t> containsBatch(const uint64_t* rows, size_t n) const
+	{
+		flush();
+		std::vector<uint8_t> out(n ? n : 1);
+		btlbf_shim::check(btlbf_contains_hashes(m_f, rows, n, out.data(), BTLBF_HOST, nullptr));
+		out.resize(n);
+		return out;
+	}
+	// every k-mer of `seq` (ntHashIterator semantics: windows with non-ACGT bytes are skipped)
+	void insertSeq(const std::string& seq)
+	{
+		flush();
+		btlbf_shim::check(btlbf_insert_seqs(m_f, seq.data(), seq.size(), nullptr, 0, BTLBF_ORDER_PARALLEL,
+		                                    BTLBF_HOST, nullptr));
+	}
+	// contains() of every window: result[p] for window start p; valid[p] = window was a clean k-mer
+	void containsSeq(const std::string& seq, std::vector<bool>& result, std::vector<bool>& valid) const
+	{
+		flush();
+		const size_t nw = (seq.size() + 63) / 64;
+		std::vector<uint64_t> hb(nw ? nw : 1), vb(nw ? nw : 1);
+		btlbf_shim::check(btlbf_contains_seqs(m_f, seq.data(), seq.size(), nullptr, hb.data(), vb.data(),
+		                                      nullptr, BTLBF_HOST, nullptr));
+		result.assign(seq.size(), false);
+		valid.assign(seq.size(), false);
+		for (size_t p = 0; p < seq.size(); ++p) {
+			result[p] = btlbf_shim::bit(hb.data(), p);
+			valid[p] = btlbf_shim::bit(vb.data(), p);
+		}
+	}
+
+	// ---- persistence ----
+	void storeFilter(const std::string& filterFilePath) const // BloomFilter.hpp:304-314
+	{
+		flush();
+		std::cerr << "Writing a " << sizeInBytes() << " byte filter to " << filterFilePath
+		          << " on disk.\n";
+		btlbf_shim::check(btlbf_store(m_f, filterFilePath.c_str()));
+	}
+	void writeHeader(std::ostream& out) const // BloomFilter.hpp:264-288
+	{
+		char buf[1024];
+		size_t n = 0;
+		btlbf_shim::check(btlbf_header(m_f, buf, sizeof buf, &n));
+		out.write(buf, (std::streamsize)n);
+	}
+	friend std::ostream& operator<<(std::ostream& out, const BloomFilter& bloom) // BloomFilter.hpp:291-297
+	{
+		bloom.flush();
+		bloom.writeHeader(out);
+		std::vector<char> chunk(1u << 24);
+		const uint64_t total = bloom.sizeInBytes();
+		for (uint64_t off = 0; off < total; off += chunk.size()) {
+			const uint64_t n = std::min<uint64_t>(chunk.size(), total - off);
+			btlbf_shim::check(btlbf_download(bloom.m_f, chunk.data(), off, n));
+			out.write(chunk.data(), (std::streamsize)n);
+		}
+		return out;
+	}
+
+	// ---- statistics and attributes ----
+	uint64_t getPop() const // BloomFilter.hpp:316-323
+	{
+		flush();
+		uint64_t v = 0;
+		btlbf_shim::check(btlbf_popcount(m_f, &v));
+		return v;
+	}
+	double getFPR() // BloomFilter.hpp:346-350
+	{
+		m_FPR = std::pow(double(getPop()) / double(getFilterSize()), double(getHashNum()));
+		return m_FPR;
+	}
+	double getFPRPrecompute() const { return m_FPR; }
+	double getFPR_numEle() const // BloomFilter.hpp:363-367,423-427
+	{
+		const double m = double(getFilterSize()), h = double(getHashNum());
+		return std::pow(1.0 - std::pow(1.0 - 1.0 / m, double(btlbf_get_n_entry(m_f)) * h), h);
+	}
+	unsigned getHashNum() const { return btlbf_hash_num(m_f); }
+	unsigned getKmerSize() const { return btlbf_kmer_size(m_f); }
+	uint64_t getFilterSize() const { return btlbf_size(m_f); }
+	uint64_t sizeInBytes() const { return btlbf_size_bytes(m_f); }
+	uint64_t getnEntry() { return btlbf_get_n_entry(m_f); }
+	uint64_t gettEntry() { return btlbf_get_t_entry(m_f); }
+	void setnEntry(uint64_t value) { btlbf_set_n_entry(m_f, value); }
+	void settEntry(uint64_t value) { btlbf_set_t_entry(m_f, value); }
+
+	// the C-ABI handle, for callers that want the raw batch entry points
+	btlbf_filter* handle() const
+	{
+		flush();
+		return m_f;
+	}
+
+  protected:
+	BloomFilter(const BloomFilter&) = delete; // BloomFilter.hpp:384
+	BloomFilter& operator=(const BloomFilter&) = delete;
+
+	void flush() const
+	{
+		if (m_pending.empty())
+			return;
+		const unsigned h = getHashNum();
+		btlbf_shim::check(btlbf_insert_hashes(m_f, m_pending.data(), m_pending.size() / h, 0,
+		                                      BTLBF_ORDER_PARALLEL, BTLBF_HOST, nullptr));
+		m_pending.clear();
+	}
+
+	static constexpr size_t kFlushRows = 1u << 16;
+	btlbf_filter* m_f = nullptr;
+	mutable std::vector<uint64_t> m_pending;
+	double m_FPR = 0;
+};
+
+#endif

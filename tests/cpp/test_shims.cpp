@@ -1,0 +1,234 @@
+// tests/cpp/test_shims.cpp -- the reference's unit-test scenarios (Tests/Unit/BloomFilterTests.cpp:69-139,
+// Tests/Unit/CountingBloomFilterTests.cpp:70-244), written against the drop-in C++ shims in
+// include/btlbf/.  A user of the reference changes only the include paths.  Needs a GPU.
+#include "btlbf/BloomFilter.hpp"
+#include "btlbf/BloomFilterUtil.h"
+#include "btlbf/CountingBloomFilter.hpp"
+#include "btlbf/KmerBloomFilter.hpp"
+#include "btlbf/ntHashIterator.hpp"
+#include "btlbf/stHashIterator.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <unistd.h>
+
+static int g_fail = 0;
+#define CHECK(cond)                                                                    \
+	do {                                                                               \
+		if (!(cond)) {                                                                 \
+			std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+			++g_fail;                                                                  \
+		}                                                                              \
+	} while (0)
+
+static std::string tmp_name(const char* tag)
+{
+	char buf[256];
+	std::snprintf(buf, sizeof buf, "/tmp/btlbf_shim_%s_%d.bf", tag, (int)getpid());
+	return buf;
+}
+
+static std::string slurp(const std::string& p)
+{
+	std::ifstream f(p, std::ios::binary);
+	std::stringstream ss;
+	ss << f.rdbuf();
+	return ss.str();
+}
+
+// returns offset of the first byte after the "[HeaderEnd]" line, 0 if absent
+static size_t header_len(const std::string& path)
+{
+	std::ifstream f(path);
+	std::string line;
+	while (std::getline(f, line))
+		if (line == "[HeaderEnd]")
+			return (size_t)f.tellg();
+	return 0;
+}
+
+static void bloom_basic()
+{
+	const size_t filterSize = 1000000000;
+	const unsigned numHashes = 5, k = 4;
+	const char* seq = "ACGTAC";
+	BloomFilter filter(filterSize, numHashes, k);
+	ntHashIterator insertIt(seq, numHashes, k);
+	unsigned n = 0;
+	while (insertIt != insertIt.end()) {
+		filter.insert(*insertIt);
+		++insertIt;
+		++n;
+	}
+	CHECK(n == 3);
+	ntHashIterator queryIt(seq, numHashes, k);
+	while (queryIt != queryIt.end()) {
+		CHECK(filter.contains(*queryIt));
+		++queryIt;
+	}
+	const std::string fn = tmp_name("bloom");
+	filter.storeFilter(fn);
+	const size_t hl = header_len(fn);
+	CHECK(hl > 0);
+	BloomFilter filter2(fn);
+	CHECK(slurp(fn).size() - hl == filter2.sizeInBytes());
+	CHECK(filter2.getFilterSize() == filterSize && filter2.getHashNum() == numHashes && filter2.getKmerSize() == k);
+	ntHashIterator q2(seq, numHashes, k);
+	while (q2 != q2.end()) {
+		CHECK(filter2.contains(*q2));
+		++q2;
+	}
+	CHECK(filter2.getPop() == filter.getPop());
+	CHECK(filter.getPop() <= 15 && filter.getPop() >= 10);
+	std::remove(fn.c_str());
+}
+
+static void hash_known_answers()
+{
+	// values observed from the reference
+	ntHashIterator it("ACGTAC", 5, 4);
+	CHECK(it.pos() == 0);
+	const uint64_t exp0[5] = {0x4b21efd76bfc8c8aULL, 0x6ab8d13c740e89beULL, 0xb5dac11e34491d35ULL,
+	                          0x00fcb0dfe49bd351ULL, 0x4c1ea0bee4de43d4ULL};
+	for (int i = 0; i < 5; ++i)
+		CHECK((*it)[i] == exp0[i]);
+	++it;
+	CHECK(it.pos() == 1 && (*it)[0] == 0x62779f381e5f5a2dULL);
+	++it;
+	CHECK(it.pos() == 2 && (*it)[0] == 0xec40e7b3741c2bddULL);
+	++it;
+	CHECK(it == ntHashIterator::end());
+	// N handling and a start offset
+	ntHashIterator jt("ACGTNACGTAC", 2, 4, 1);
+	CHECK(jt.pos() == 5);
+	ntHashIterator kt("ACG", 1, 4);
+	CHECK(kt == ntHashIterator::end());
+	// spaced seeds, toy case of SURVEY.md 8c
+	std::vector<std::string> seeds = {"1110111", "1011101"};
+	stHashIterator st("ACGTNACGTACGTACGGTCA", stHashIterator::parseSeed(seeds), 2, 2, 7);
+	CHECK(st.pos() == 5);
+	const uint64_t exps[4] = {0x589d161199065de2ULL, 0xda4f3c83d59781ddULL, 0xb96a9e21deae3f34ULL,
+	                          0x5ae90c2e2b2dbc02ULL};
+	const bool expst[4] = {true, true, false, false};
+	for (int i = 0; i < 4; ++i) {
+		CHECK((*st)[i] == exps[i]);
+		CHECK(st.strandArray()[i] == expst[i]);
+	}
+}
+
+static void counting_basic()
+{
+	const size_t sizeInBytes = 100001;
+	const unsigned numHashes = 5, k = 8, threshold = 1;
+	const char* seq = "ACGTACACTGGACTGAGTCT";
+	CountingBloomFilter<uint8_t> filter(sizeInBytes, numHashes, k, threshold);
+	CHECK(filter.sizeInBytes() == 100008 && filter.size() == 100008);
+	ntHashIterator insertIt(seq, numHashes, k);
+	while (insertIt != insertIt.end()) {
+		filter.insert(*insertIt);
+		++insertIt;
+	}
+	ntHashIterator queryIt(seq, numHashes, k);
+	unsigned n = 0;
+	while (queryIt != queryIt.end()) {
+		CHECK(filter.contains(*queryIt));
+		CHECK(filter.minCount(*queryIt) >= 1);
+		++queryIt;
+		++n;
+	}
+	CHECK(n == 13);
+	// a different sequence is (with overwhelming probability) absent
+	const std::string other = "TTGACCAGTTACGGATCCAGTAGGCATTAGCCATGATCGGGATACCATGAACTTGACTGA";
+	ntHashIterator o(other, numHashes, k);
+	while (o != o.end()) {
+		CHECK(!filter.contains(*o));
+		++o;
+	}
+	// incrementAll / insertAndCheck / operator[]
+	std::vector<uint64_t> hv = {1, 100009, 2, 3, 4}; // positions 1,1,2,3,4 modulo 100008
+	filter.incrementAll(hv);
+	CHECK(filter[1] >= 2 && filter[2] >= 1);
+	CHECK(filter.insertAndCheck(hv));
+	const std::string fn = tmp_name("cbf");
+	filter.storeFilter(fn);
+	const size_t hl = header_len(fn);
+	CHECK(hl > 0 && slurp(fn).size() - hl == filter.sizeInBytes());
+	CountingBloomFilter<uint8_t> filter2(fn, threshold);
+	CHECK(filter2.size() * sizeof(uint8_t) == filter2.sizeInBytes());
+	CHECK(filter2.popCount() == filter.popCount() && filter2.filtered_popcount() == filter.filtered_popcount());
+	ntHashIterator q2(seq, numHashes, k);
+	while (q2 != q2.end()) {
+		CHECK(filter2.contains(*q2));
+		++q2;
+	}
+	std::remove(fn.c_str());
+}
+
+static void fused_path_equals_iterator_path(const char* golden_dir)
+{
+	const std::string seq = "GATTACAGATTACANNGATTACACCCGGGTTTAAACGTACGTTGCAAGCTTAGGCTAACGTAGCTAGCTAGGATCCGAT"
+	                        "CGATCGGGATATATCGCGCTAGCTAGCATCGATCGTAGCTAGTCGATCGATGCTAGCTAGCTAGCTAGCATGCATGCA";
+	const unsigned h = 4, k = 31;
+	KmerBloomFilter a(1 << 16, h, k), b(1 << 16, h, k), c(1 << 16, h, k);
+	insertSeq(a, seq, h, k); // one fused launch
+	ntHashIterator it(seq, h, k);
+	while (it != it.end()) { // literal reference loop
+		b.insert(*it);
+		++it;
+	}
+	for (size_t p = 0; p + k <= seq.size(); ++p) { // raw k-mer strings
+		const std::string km = seq.substr(p, k);
+		if (km.find('N') == std::string::npos)
+			c.insert(km.c_str());
+	}
+	const std::string fa = tmp_name("fa"), fb = tmp_name("fb"), fc = tmp_name("fc");
+	a.storeFilter(fa);
+	b.storeFilter(fb);
+	c.storeFilter(fc);
+	CHECK(slurp(fa) == slurp(fb));
+	CHECK(slurp(fa) == slurp(fc));
+	CHECK(a.contains(seq.substr(40, k).c_str()));
+	std::vector<bool> res, valid;
+	a.containsSeq(seq, res, valid);
+	size_t nv = 0;
+	for (size_t p = 0; p < seq.size(); ++p) {
+		CHECK(res[p] == valid[p]);
+		nv += valid[p];
+	}
+	CHECK(nv > 0 && nv < seq.size() - k + 1); // the N run removes some windows
+	// operator<< writes the same bytes as storeFilter
+	std::ostringstream os;
+	os << a;
+	CHECK(os.str() == slurp(fa));
+	std::remove(fa.c_str());
+	std::remove(fb.c_str());
+	std::remove(fc.c_str());
+	// a file written by the genuine reference round-trips byte for byte
+	if (golden_dir) {
+		const std::string g = std::string(golden_dir) + "/bf_1000_k25_h3_entries.bf";
+		BloomFilter f(g);
+		CHECK(f.getnEntry() == 17 && f.gettEntry() == 123456789012ULL);
+		const std::string out = tmp_name("golden");
+		f.storeFilter(out);
+		CHECK(slurp(out) == slurp(g));
+		std::remove(out.c_str());
+	}
+}
+
+int main(int argc, char** argv)
+{
+	bloom_basic();
+	hash_known_answers();
+	counting_basic();
+	fused_path_equals_iterator_path(argc > 1 ? argv[1] : nullptr);
+	if (g_fail) {
+		std::fprintf(stderr, "%d checks failed\n", g_fail);
+		return 1;
+	}
+	std::printf("all shim tests passed\n");
+	return 0;
+}

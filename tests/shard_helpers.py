@@ -1,0 +1,146 @@
+"""Helpers for the multi-rank tests: a CPU stand-in for the per-rank compute (built on the test-only
+oracle) so that the routing logic of btl_bloomfilter_amd.sharded can run under gloo without a GPU,
+and the worker functions spawned per rank."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class OracleShardOps:
+    """same interface as sharded.HipShardOps, computed with oracle/btl_oracle.c on CPU tensors"""
+
+    def __init__(self, global_bits, h, k, rank, world):
+        from oracle.pyoracle import Oracle
+
+        self.o = Oracle()
+        self.bits, self.h, self.k, self.rank, self.world = global_bits, h, k, rank, world
+        self.shard_len = global_bits // world
+        self.body = np.zeros(self.shard_len // 8, np.uint8)
+        self.device = torch.device("cpu")
+
+    def clear(self):
+        self.body[:] = 0
+
+    def positions(self, reads, read_len, cap, want_tags):
+        buf = reads.numpy()
+        n = buf.size
+        buckets = np.zeros((self.world, cap), np.int64)
+        tags = np.zeros((self.world, cap), np.int64)
+        counts = np.zeros(self.world, np.int64)
+        valid = np.zeros(n, np.uint8)
+        for r in range(n // read_len):
+            pos, hv = self.o.nthash_seq(buf[r * read_len:(r + 1) * read_len].tobytes(), self.h, self.k)
+            for p, row in zip(pos, hv):
+                gp = r * read_len + int(p)
+                valid[gp] = 1
+                for i, x in enumerate(row):
+                    q = int(x) % self.bits
+                    own = q // self.shard_len
+                    c = counts[own]
+                    if c < cap:
+                        buckets[own, c] = q - own * self.shard_len
+                        tags[own, c] = gp * self.h + i
+                    counts[own] += 1
+        vb = np.packbits(np.concatenate([valid, np.zeros((-n) % 64, np.uint8)]), bitorder="little").view(np.int64)
+        return (torch.from_numpy(buckets), torch.from_numpy(tags) if want_tags else None, torch.from_numpy(counts),
+                torch.from_numpy(vb.copy()) if want_tags else None)
+
+    def insert_positions(self, pos):
+        p = pos.numpy().astype(np.uint64)
+        np.bitwise_or.at(self.body, (p >> np.uint64(3)).astype(np.int64), (1 << (p & np.uint64(7))).astype(np.uint8))
+
+    def test_positions(self, pos):
+        p = pos.numpy().astype(np.uint64)
+        return torch.from_numpy(((self.body[(p >> np.uint64(3)).astype(np.int64)] >> (p & np.uint64(7)).astype(np.uint8)) & 1).astype(np.uint8))
+
+    def and_answers(self, tags, answers, hit_bits):
+        t, a = tags.numpy(), answers.numpy()
+        hb = hit_bits.numpy().view(np.uint64)
+        for tag in t[a == 0]:
+            p = int(tag) // self.h
+            hb[p >> 6] &= ~np.uint64(1 << (p & 63))
+
+    def popcount_bits(self, bits):
+        return int(np.unpackbits(bits.numpy().view(np.uint8)).sum())
+
+    def local_body(self):
+        return self.body.copy()
+
+
+def _init(rank, world, port, backend="gloo"):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+
+
+def cpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
+    """gloo + oracle stand-in: validates bucketing / all-to-all / answer routing"""
+    from oracle.pyoracle import Oracle
+
+    from btl_bloomfilter_amd.sharded import ShardedBloomFilter
+
+    _init(rank, world, port)
+    o = Oracle()
+    ops = OracleShardOps(bits, h, k, rank, world)
+    f = ShardedBloomFilter(bits, h, k, ops=ops, batch_reads=64)
+    mine = torch.from_numpy(o.synth_reads(42, rank * n_reads, n_reads, read_len))
+    f.insert_reads(mine, read_len)
+    dist.barrier()
+    np.save(os.path.join(outdir, "body%d.npy" % rank), ops.local_body())
+    # query: own reads (hits) followed by reads nobody inserted
+    q = torch.from_numpy(np.concatenate([o.synth_reads(42, rank * n_reads, n_reads, read_len),
+                                         o.synth_reads(43, rank * n_reads, n_reads, read_len)]))
+    hit = torch.zeros((q.numel() + 63) // 64, dtype=torch.int64)
+    cnt = torch.zeros(2, dtype=torch.int64)
+    f.contains_reads(q, read_len, hit, cnt)
+    np.save(os.path.join(outdir, "hit%d.npy" % rank), hit.numpy())
+    np.save(os.path.join(outdir, "cnt%d.npy" % rank), cnt.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
+    """gloo (host-staged exchange) + the real HIP kernels, all ranks on cuda:0"""
+    import btl_bloomfilter_amd as m
+    from btl_bloomfilter_amd.sharded import ShardedBloomFilter
+
+    torch.cuda.set_device(0)
+    _init(rank, world, port)
+    f = ShardedBloomFilter(bits, h, k, device=0, batch_reads=4096)
+    mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
+    f.insert_reads(mine, read_len)
+    torch.cuda.synchronize()
+    dist.barrier()
+    np.save(os.path.join(outdir, "body%d.npy" % rank), f.ops.local_body())
+    f.store(os.path.join(outdir, "sharded.bf"))
+    q = torch.cat([mine, m.synth_reads_device(43, rank * n_reads, n_reads, read_len)])
+    hit = torch.zeros((q.numel() + 63) // 64, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int64)
+    f.contains_reads(q, read_len, hit, cnt)
+    torch.cuda.synchronize()
+    np.save(os.path.join(outdir, "hit%d.npy" % rank), hit.cpu().numpy())
+    np.save(os.path.join(outdir, "cnt%d.npy" % rank), cnt.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()

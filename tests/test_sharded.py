@@ -1,0 +1,86 @@
+"""Multi-rank path (hash-range shards + all-to-all routing).
+
+CPU: world_size 2 under gloo with an oracle-backed stand-in for the per-rank kernels -- checks that
+the routing produces the single-filter body and the single-filter contains() answers.
+GPU: the same with the real HIP kernels (both ranks on the one GPU of the test box, exchange staged
+through the host by gloo), checked against the golden digest of the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+from shard_helpers import cpu_worker, free_port, gpu_worker, sha
+
+
+def expected(oracle, bits, h, k, world, n_reads, L):
+    body = np.zeros(bits // 8, np.uint8)
+    for r in oracle.synth_reads(42, 0, world * n_reads, L).reshape(-1, L):
+        oracle.bf_insert_seq(body, bits, h, k, r.tobytes())
+    return body
+
+
+def check_queries(oracle, body, bits, h, k, world, n_reads, L, outdir):
+    for rank in range(world):
+        q = np.concatenate([oracle.synth_reads(42, rank * n_reads, n_reads, L), oracle.synth_reads(43, rank * n_reads, n_reads, L)])
+        eh, ev = [], []
+        for r in q.reshape(-1, L):
+            a, b = oracle.bf_contains_seq_dense(body, bits, h, k, r.tobytes())
+            eh.append(np.concatenate([a, np.zeros(k - 1, np.uint8)]))
+            ev.append(np.concatenate([b, np.zeros(k - 1, np.uint8)]))
+        eh, ev = np.concatenate(eh), np.concatenate(ev)
+        hit = np.unpackbits(np.load(os.path.join(outdir, "hit%d.npy" % rank)).view(np.uint8), bitorder="little")[: q.size]
+        assert (hit == eh).all(), rank
+        cnt = np.load(os.path.join(outdir, "cnt%d.npy" % rank))
+        assert cnt.tolist() == [int(ev.sum()), int(eh.sum())]
+        assert eh[: n_reads * L].sum() == n_reads * (L - k + 1)  # own reads: no false negatives
+
+
+def test_sharded_routing_gloo_cpu(oracle, tmp_path):
+    bits, h, k, world, n_reads, L = 1 << 16, 4, 31, 2, 128, 150
+    mp.spawn(cpu_worker, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L), nprocs=world, join=True)
+    body = expected(oracle, bits, h, k, world, n_reads, L)
+    got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+    assert (got == body).all(), "concatenated shard bodies differ from the single-filter body"
+    check_queries(oracle, body, bits, h, k, world, n_reads, L, str(tmp_path))
+
+
+def test_sharded_world1_matches_plain_filter_cpu(oracle):
+    """world_size 1 without a process group: the same code path degenerates to a plain filter"""
+    import torch
+
+    from btl_bloomfilter_amd.sharded import ShardedBloomFilter
+    from shard_helpers import OracleShardOps
+
+    bits, h, k, L, n = 1 << 14, 3, 25, 100, 40
+    ops = OracleShardOps(bits, h, k, 0, 1)
+    f = ShardedBloomFilter(bits, h, k, ops=ops, batch_reads=16)
+    reads = oracle.synth_reads(7, 0, n, L)
+    f.insert_reads(torch.from_numpy(reads), L)
+    body = np.zeros(bits // 8, np.uint8)
+    for r in reads.reshape(-1, L):
+        oracle.bf_insert_seq(body, bits, h, k, r.tobytes())
+    assert (ops.local_body() == body).all()
+
+
+@pytest.mark.gpu
+def test_sharded_hip_two_ranks_one_gpu(oracle, tmp_path):
+    g = load_golden("digests.json")["bf_small"]  # 20000 reads, 2^24 bits, k=31, h=4 (genuine reference)
+    bits, h, k, L, world = g["bits"], g["h"], g["k"], g["read_len"], 2
+    n_reads = g["n_reads"] // world
+    mp.spawn(gpu_worker, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+    assert sha(got) == g["body_sha256"]
+    raw = open(tmp_path / "sharded.bf", "rb").read()
+    i = raw.index(b"[HeaderEnd]\n") + 12
+    assert raw[:i] == oracle.bf_header(bits, h, k) and sha(np.frombuffer(raw[i:], np.uint8)) == g["body_sha256"]
+    # contains(): first 64 reads of every rank checked window by window, totals for the rest
+    for rank in range(world):
+        cnt = np.load(tmp_path / ("cnt%d.npy" % rank))
+        assert cnt[0] == 2 * n_reads * (L - k + 1) and cnt[1] >= n_reads * (L - k + 1)
+        hit = np.unpackbits(np.load(tmp_path / ("hit%d.npy" % rank)).view(np.uint8), bitorder="little")
+        q = oracle.synth_reads(42, rank * n_reads, 64, L)
+        for j, r in enumerate(q.reshape(-1, L)):
+            a, _ = oracle.bf_contains_seq_dense(got, bits, h, k, r.tobytes())
+            assert (hit[j * L: j * L + len(a)] == a).all()
