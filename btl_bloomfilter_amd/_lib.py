@@ -12,6 +12,7 @@ BLOOM, COUNTING8 = 0, 1
 INCREMENT_MIN, INCREMENT_ALL = 0, 1
 ORDER_PARALLEL, ORDER_SERIAL = 0, 1
 OK, EINVAL, ENOMEM, EIO, EFORMAT, EHIP = range(6)
+INSERT_AUTO, INSERT_DIRECT, INSERT_PARTITIONED = 0, 1, 2
 
 
 class Layout(C.Structure):
@@ -55,6 +56,7 @@ _PROTOS = {
     "btlbf_clear": (C.c_int, [_P, _P]),
     "btlbf_upload": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     "btlbf_download": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
+    "btlbf_set_insert_mode": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "btlbf_set_spaced_seeds": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_uint, C.c_uint]),
     "btlbf_insert_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_int, C.c_int, C.c_int, _P]),
     "btlbf_contains_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), _P, _P, _P, C.c_int, _P]),

@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbtlbf.so")
-SOURCES = ["capi.cpp", "seq_kernels.hip", "aux_kernels.hip"]
-HEADERS = ["internal.hpp", "device_utils.hpp", os.path.join("..", "..", "include", "btlbf.h")]
+SOURCES = ["capi.cpp", "seq_kernels.hip", "aux_kernels.hip", "partition_kernels.hip"]
+HEADERS = ["internal.hpp", "device_utils.hpp", "seq_core.hpp", os.path.join("..", "..", "include", "btlbf.h")]
 
 
 def stale():

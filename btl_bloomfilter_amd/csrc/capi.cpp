@@ -7,7 +7,9 @@
 #include "../../include/btlbf.h"
 #include "internal.hpp"
 
+#include <algorithm>
 #include <cerrno>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -74,6 +76,11 @@ struct btlbf_filter {
 	uint16_t* d_dc_idx = nullptr;
 	// small device scratch for counters
 	unsigned long long* d_scalar = nullptr; // 4 x u64
+	// partitioned insert (partition_kernels.hip): mode + cached scratch
+	int insert_mode = BTLBF_INSERT_AUTO;
+	void* d_part = nullptr;
+	uint64_t part_bytes = 0;
+	uint64_t part_budget = 0; // 0 = derive from free HBM
 };
 
 namespace {
@@ -384,6 +391,12 @@ int make_filter(btlbf_filter** out, int kind, uint64_t size, uint64_t size_bytes
 	f->alloc_bytes = (f->local_bytes + 15) / 16 * 16;
 	fill_mod(f->mod, size, (uint64_t)shard_index * len, len);
 	fill_hash_params(f->hp, k, h);
+	if (const char* m = getenv("BTLBF_INSERT_MODE")) {
+		if (!strcmp(m, "direct"))
+			f->insert_mode = BTLBF_INSERT_DIRECT;
+		else if (!strcmp(m, "partitioned"))
+			f->insert_mode = BTLBF_INSERT_PARTITIONED;
+	}
 	hipError_t e = hipMalloc(&f->d_data, f->alloc_bytes);
 	if (e != hipSuccess) {
 		delete f;
@@ -513,7 +526,17 @@ extern "C" int btlbf_destroy(btlbf_filter* f)
 	(void)hipFree(f->d_scalar);
 	(void)hipFree(f->d_pos_tab);
 	(void)hipFree(f->d_dc_idx);
+	(void)hipFree(f->d_part);
 	delete f;
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch_bytes)
+{
+	if (!f || mode < BTLBF_INSERT_AUTO || mode > BTLBF_INSERT_PARTITIONED)
+		return fail(BTLBF_EINVAL, "bad insert mode");
+	f->insert_mode = mode;
+	f->part_budget = scratch_bytes;
 	return BTLBF_OK;
 }
 
@@ -825,6 +848,131 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 
 } // namespace
 
+namespace {
+
+// Geometry, capacities and batch size of the partitioned insert for `total_tiles` tiles of
+// part_tile_windows() windows.  Returns false if the filter shape is not
+// supported (then the direct kernel is used).
+struct PartPlan {
+	PartArgs pa;
+	uint64_t tiles_per_batch;
+	uint64_t bytes_cur0, bytes_cur1, bytes_out0, bytes_out1, bytes_total;
+};
+
+uint32_t chunks_for(double mean_entries, uint32_t tail_chunks)
+{
+	const double m = mean_entries + 8.0 * std::sqrt(mean_entries + 1.0) + 32.0;
+	return (uint32_t)std::min<double>(4.0e9, std::ceil(m / 32.0)) + tail_chunks;
+}
+
+bool plan_partition(const btlbf_filter* f, uint64_t total_tiles, double probes_per_tile, unsigned blocks_a,
+                    uint64_t budget, PartPlan& pl)
+{
+	const uint64_t mloc = f->mod.shard_len;
+	PartArgs& pa = pl.pa;
+	memset(&pa, 0, sizeof pa);
+	pa.seg_shift = 19;
+	if (((mloc + (1ull << 19) - 1) >> 19) > 1024ull * 1024)
+		pa.seg_shift = 20;
+	pa.n_seg = (mloc + (1ull << pa.seg_shift) - 1) >> pa.seg_shift;
+	if (pa.n_seg > 1024ull * 1024)
+		return false;
+	pa.levels = pa.n_seg <= 1024 ? 1 : 2;
+	pa.p1 = pa.levels == 2 ? 1024 : 1;
+	pa.p0 = (uint32_t)(pa.levels == 2 ? (pa.n_seg + 1023) / 1024 : pa.n_seg);
+	pa.bin_shift = pa.seg_shift + (pa.levels == 2 ? 10 : 0);
+	uint64_t tiles = total_tiles;
+	for (int iter = 0; iter < 64; ++iter) {
+		const double nb = (double)tiles * probes_per_tile;
+		pa.cap0 = chunks_for(nb / pa.p0, blocks_a + 1);
+		pa.cap1 = pa.levels == 2 ? chunks_for(nb / (double)pa.n_seg, 2) : 0;
+		pl.bytes_cur0 = ((uint64_t)pa.p0 * 4 + 255) / 256 * 256;
+		pl.bytes_cur1 = pa.levels == 2 ? (uint64_t)pa.p0 * pa.p1 * 4 : 0;
+		pl.bytes_out0 = (uint64_t)pa.p0 * pa.cap0 * 128;
+		pl.bytes_out1 = pa.levels == 2 ? (uint64_t)pa.p0 * pa.p1 * pa.cap1 * 128 : 0;
+		pl.bytes_total = pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0 + pl.bytes_out1;
+		if (pl.bytes_total <= budget || tiles <= 1)
+			break;
+		// shrink the batch in proportion (plus a little) and try again
+		const double ratio = (double)budget / (double)pl.bytes_total;
+		uint64_t nt = (uint64_t)((double)tiles * ratio * 0.95);
+		tiles = nt >= tiles ? tiles - 1 : (nt ? nt : 1);
+	}
+	pl.tiles_per_batch = tiles;
+	return pl.bytes_total <= budget;
+}
+
+// decide between the direct (atomicOr per probe) and the partitioned insert
+bool want_partitioned(const btlbf_filter* f, uint64_t len)
+{
+	if (f->kind != BTLBF_BLOOM || f->insert_mode == BTLBF_INSERT_DIRECT)
+		return false;
+	if (!part_supported_h(f->hp.h) || len == 0)
+		return false;
+	if (f->insert_mode == BTLBF_INSERT_PARTITIONED)
+		return true;
+	// auto: one sweep of the local array (read + write) must be cheaper than the random atomics it
+	// replaces: ~ 2*bytes/5e12 s against probes/21e9 s, with a 2x margin
+	return (double)len * f->hp.h >= 0.02 * (double)f->local_bytes;
+}
+
+int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* done)
+{
+	*done = false;
+	const uint64_t tile_w = (uint64_t)part_tile_windows();
+	const uint64_t total_tiles = (base.len + tile_w - 1) / tile_w;
+	int cus = 256;
+	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, f->device);
+	const unsigned blocks_a = (unsigned)cus; // one workgroup per CU (LDS-bound)
+	double frac = 1.0;
+	if (!base.layout.starts && base.layout.read_len) {
+		const double L = base.layout.read_len;
+		frac = L >= f->hp.k ? (L - f->hp.k + 1) / L : 0.0;
+	}
+	const double probes_per_tile = (double)tile_w * f->hp.h * frac + 1.0;
+	uint64_t budget = f->part_budget;
+	if (budget == 0) {
+		size_t free_b = 0, total_b = 0;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		budget = (uint64_t)((double)(free_b + f->part_bytes) * 0.80);
+	}
+	PartPlan pl;
+	if (!plan_partition(f, total_tiles, probes_per_tile, blocks_a, budget, pl))
+		return BTLBF_OK; // not applicable: caller falls back to the direct kernel
+	if (part_hash_lds_bytes(f->hp, pl.pa.p0) > 160 * 1024)
+		return BTLBF_OK;
+	if (pl.bytes_total > f->part_bytes) {
+		(void)hipFree(f->d_part);
+		f->d_part = nullptr;
+		f->part_bytes = 0;
+		hipError_t e = hipMalloc(&f->d_part, pl.bytes_total);
+		if (e != hipSuccess) {
+			(void)hipGetLastError();
+			return BTLBF_OK; // no room for scratch: direct kernel
+		}
+		f->part_bytes = pl.bytes_total;
+	}
+	uint8_t* p = static_cast<uint8_t*>(f->d_part);
+	pl.pa.cur0 = reinterpret_cast<uint32_t*>(p);
+	pl.pa.cur1 = reinterpret_cast<uint32_t*>(p + pl.bytes_cur0);
+	pl.pa.out0 = reinterpret_cast<uint32_t*>(p + pl.bytes_cur0 + pl.bytes_cur1);
+	pl.pa.out1 = reinterpret_cast<uint32_t*>(p + pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0);
+	for (uint64_t t0 = 0; t0 < total_tiles; t0 += pl.tiles_per_batch) {
+		SeqArgs a = base;
+		a.first_tile = t0;
+		a.n_tiles = std::min<uint64_t>(pl.tiles_per_batch, total_tiles - t0);
+		HIP_TRY(hipMemsetAsync(p, 0, pl.bytes_cur0 + pl.bytes_cur1, s));
+		HIP_TRY(launch_part_hash(a, pl.pa, blocks_a, s));
+		if (pl.pa.levels == 2)
+			HIP_TRY(launch_part_split(f->d_data, pl.pa, s));
+		HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, s));
+	}
+	*done = true;
+	return BTLBF_OK;
+}
+
+} // namespace
+
 extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
                                  const btlbf_layout* layout, int op, int order, int mem, void* stream)
 {
@@ -841,6 +989,17 @@ extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
 	int kop;
 	if (f->kind == BTLBF_BLOOM) {
 		kop = OP_BF_INSERT; // bit OR is order-free: serial order would give the same bytes
+		if (want_partitioned(f, len)) {
+			bool done = false;
+			rc = partitioned_insert(f, a, s, &done);
+			if (rc)
+				return rc;
+			if (done) {
+				if (mem == BTLBF_HOST)
+					HIP_TRY(hipStreamSynchronize(s));
+				return BTLBF_OK;
+			}
+		}
 	} else {
 		if (f->shard_count != 1)
 			return fail(BTLBF_EINVAL, "counting filters are not sharded in this version");

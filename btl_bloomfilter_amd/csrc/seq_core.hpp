@@ -1,0 +1,266 @@
+// csrc/seq_core.hpp -- the shared front end of every sequence kernel: tile staging and the
+// per-lane rolling ntHash.  Used by seq_kernels.hip (fused hash + probe) and partition_kernels.hip
+// (fused hash + radix partition).
+//
+// A tile is NT*kW consecutive window start offsets (NT = workgroup size, kW = 8 windows per lane).
+//   seq_setup_tables : one-time LDS tables (byte -> base code LUT, Horner/roll seed tables, spaced-seed tables)
+//   seq_stage_tile   : coalesced 16-byte loads of the tile's bytes -> LDS byte per base
+//                      (bits 2:0 code, bit 3 valid, bit 4 first base of a sequence)
+//   seq_lane_windows : Horner start-up over the lane's first window, then kW-1 O(1) rolls; calls
+//                      f(w, clean, hashes) for each of the lane's windows
+// Reference semantics reproduced (not its code): ntHashIterator init/next
+// (vendor/ntHashIterator.hpp:59-86), NTMC64/NTMSM64 (vendor/nthash.hpp:581-590,667-692,820-878).
+#pragma once
+#include "device_utils.hpp"
+
+namespace btlbf {
+
+static constexpr int kW = 8; // consecutive windows per lane
+
+struct __attribute__((aligned(16))) U64x2 {
+	uint64_t x, y;
+};
+
+// static LDS shared by the sequence kernels
+struct SeqShared {
+	U64x2 init_tab[kNumCodes];
+	U64x2 in_tab[kNumCodes];
+	U64x2 out_tab[kNumCodes];
+	uint8_t lut[256];
+	unsigned long long cnt_valid;
+	unsigned long long cnt_hit;
+	uint64_t start_lo; // ragged layout: first starts[] index that can fall inside the tile
+};
+
+// ASCII byte -> code | valid (what vendor/nthash.hpp:195-228 accepts: ACGTU acgtu and 1 3 4 5 7)
+__device__ __forceinline__ uint8_t base_entry(uint32_t c)
+{
+	switch (c) {
+	case 'A': case 'a': return 0 | kBaseValid;
+	case 'C': case 'c': return 1 | kBaseValid;
+	case 'G': case 'g': return 2 | kBaseValid;
+	case 'T': case 't': case 'U': case 'u': return 3 | kBaseValid;
+	case 4: case 5: return 4 | kBaseValid; // raw bytes: forward A C G T, reverse seed = forward seed
+	case 7: return 5 | kBaseValid;
+	case 3: return 6 | kBaseValid;
+	case 1: return 7 | kBaseValid;
+	default: return 0;
+	}
+}
+
+// bytes of dynamic LDS the tile needs (tile bytes + up to 15 bytes of misalignment, rounded to 16)
+__host__ __device__ inline uint32_t seq_tile_cap(uint32_t tile_windows, uint32_t k)
+{
+	return ((tile_windows + k - 1 + 15 + 15) / 16) * 16;
+}
+// bytes of dynamic LDS for the spaced-seed tables that follow the tile
+__host__ __device__ inline uint32_t seq_spaced_bytes(const HashParams& hp)
+{
+	if (hp.n_seeds == 0)
+		return 0;
+	return hp.k * kNumCodes * 16 + ((hp.dc_off[hp.n_seeds] * 2 + 15) / 16) * 16;
+}
+
+// one-time table setup; callers __syncthreads() before first use (seq_stage_tile does)
+template <int NT, bool SPACED>
+__device__ __forceinline__ void seq_setup_tables(SeqShared& sh, const HashParams& hp, uint8_t* spaced_lds)
+{
+	const uint32_t tid = threadIdx.x;
+	for (uint32_t i = tid; i < 256; i += NT)
+		sh.lut[i] = base_entry(i);
+	if (tid < kNumCodes) {
+		sh.init_tab[tid] = U64x2{hp.init_tab[tid][0], hp.init_tab[tid][1]};
+		sh.in_tab[tid] = U64x2{hp.in_tab[tid][0], hp.in_tab[tid][1]};
+		sh.out_tab[tid] = U64x2{hp.out_tab[tid][0], hp.out_tab[tid][1]};
+	}
+	if (tid == 0) {
+		sh.cnt_valid = 0;
+		sh.cnt_hit = 0;
+	}
+	if (SPACED) {
+		const uint32_t k = hp.k;
+		uint64_t* pt = reinterpret_cast<uint64_t*>(spaced_lds);
+		for (uint32_t i = tid; i < k * kNumCodes * 2; i += NT)
+			pt[i] = hp.pos_tab[i];
+		uint16_t* di = reinterpret_cast<uint16_t*>(spaced_lds + k * kNumCodes * 16);
+		const uint32_t ndc = hp.dc_off[hp.n_seeds];
+		for (uint32_t i = tid; i < ndc; i += NT)
+			di[i] = hp.dc_idx[i];
+	}
+}
+
+// Stage the tile that starts at byte offset g0.  Ends with a __syncthreads(); begins with one so
+// that the previous tile has been fully consumed.  tile_off = g0 % read_len (uniform layout only).
+// Returns the misalignment `mis`: LDS index of window w's first base is w + mis.
+template <int NT>
+__device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_cap, SeqShared& sh,
+                                                   const uint8_t* seq, uint64_t len, const LayoutParams& lay,
+                                                   uint32_t k, uint64_t g0, uint32_t tile_off)
+{
+	constexpr uint32_t kTileW = NT * kW;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t L = lay.read_len;
+	const uint64_t* starts = lay.starts;
+	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(seq + g0) & 15);
+	uint64_t need = len - g0;
+	if (need > (uint64_t)(kTileW + k - 1))
+		need = kTileW + k - 1;
+	const uint32_t n_chunks = (mis + (uint32_t)need + 15) / 16;
+	__syncthreads(); // previous tile fully consumed (and tables written, first time round)
+
+	// chunks past the data are zero-filled so no stale flags survive
+	for (uint32_t j = tid; j < tile_cap / 16; j += NT) {
+		uint4 raw = make_uint4(0, 0, 0, 0);
+		if (j < n_chunks)
+			raw = *reinterpret_cast<const uint4*>(seq + g0 - mis + 16ull * j);
+		const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
+		// position of this chunk's first byte relative to g0 (negative for the misaligned head)
+		const int32_t rel0 = (int32_t)(16 * j) - (int32_t)mis;
+		uint32_t r = 0; // (offset within read) of the chunk's first byte, uniform layout only
+		if (!starts && L) {
+			const uint32_t m = mis % L;
+			r = ((tile_off + 16 * j) % L + L - m) % L;
+		}
+		uint32_t outw[4];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			uint32_t o = 0;
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				const int32_t rel = rel0 + q * 4 + b;
+				uint32_t e = sh.lut[(wv[q] >> (8 * b)) & 0xff];
+				if (rel < 0 || (uint64_t)rel >= need)
+					e = 0;
+				if (!starts && L) {
+					if (r == 0)
+						e |= kBaseStart;
+					r = (r + 1 == L) ? 0 : r + 1;
+				}
+				o |= e << (8 * b);
+			}
+			outw[q] = o;
+		}
+		*reinterpret_cast<uint4*>(tile + 16 * j) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+	}
+	if (starts) {
+		// first index s with starts[s] > g0: every boundary strictly inside (g0, g0+need) matters
+		if (tid == 0) {
+			uint64_t lo = 0, hi = lay.n_seqs + 1;
+			while (lo < hi) {
+				uint64_t mid = (lo + hi) >> 1;
+				if (starts[mid] > g0)
+					hi = mid;
+				else
+					lo = mid + 1;
+			}
+			sh.start_lo = lo;
+		}
+		__syncthreads();
+		const uint64_t s_lo = sh.start_lo;
+		for (uint64_t s = s_lo + tid; s <= lay.n_seqs; s += NT) {
+			const uint64_t p = starts[s];
+			if (p >= g0 + need)
+				break;
+			const uint32_t li = (uint32_t)(p - g0) + mis;
+			atomicOr(reinterpret_cast<uint32_t*>(tile) + (li >> 2), kBaseStart << (8 * (li & 3)));
+		}
+	}
+	__syncthreads();
+	return mis;
+}
+
+// hash values of one window.  Plain ntHash: hash i is recomputed from the canonical value where it
+// is needed (a multiply and a shift), so nothing is indexed dynamically; spaced seeds keep an array.
+template <bool SPACED>
+struct WinHash {
+	uint64_t bcan;
+	uint64_t kms;
+	uint32_t stn; // strand flags (spaced seeds), bit i = hash i came from the reverse strand
+	uint64_t hv[SPACED ? kMaxHash : 1];
+	__device__ __forceinline__ uint64_t at(uint32_t i) const
+	{
+		if (SPACED)
+			return hv[SPACED ? i : 0];
+		return i ? extra_hash(bcan, kms, i) : bcan;
+	}
+};
+
+// Walk the lane's kW consecutive windows (first base at LDS index li0) and call
+// f(w, clean, const WinHash<SPACED>&) for each.
+template <bool SPACED, class F>
+__device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqShared& sh, const HashParams& hp,
+                                                 const uint8_t* spaced_lds, uint32_t li0, F&& f)
+{
+	const uint32_t k = hp.k;
+	const U64x2* pos_tab = reinterpret_cast<const U64x2*>(spaced_lds);
+	const uint16_t* dc_idx = reinterpret_cast<const uint16_t*>(spaced_lds + (SPACED ? k * kNumCodes * 16 : 0));
+	uint64_t fh, rh;
+	uint32_t cnt = 0; // valid, non-start bases among the k-1 bases after the window's first
+	uint32_t first_valid;
+	{
+		uint32_t e = tile[li0];
+		first_valid = (e >> 3) & 1;
+		U64x2 tt = sh.init_tab[e & kCodeMask];
+		fh = tt.x;
+		rh = tt.y;
+		for (uint32_t i = 1; i < k; ++i) {
+			e = tile[li0 + i];
+			tt = sh.init_tab[e & kCodeMask];
+			fh = srol1(fh) ^ tt.x;
+			rh = sror1(rh) ^ tt.y;
+			cnt += ((e & (kBaseValid | kBaseStart)) == kBaseValid);
+		}
+	}
+#pragma unroll
+	for (int w = 0; w < kW; ++w) {
+		if (w > 0) {
+			const uint32_t eo = tile[li0 + w - 1];
+			const uint32_t ei = tile[li0 + w - 1 + k];
+			const uint32_t en = tile[li0 + w];
+			const U64x2 ti = sh.in_tab[ei & kCodeMask];
+			const U64x2 to = sh.out_tab[eo & kCodeMask];
+			fh = srol1(fh) ^ ti.x ^ to.x;
+			rh = sror1(rh ^ ti.y ^ to.y);
+			cnt += ((ei & (kBaseValid | kBaseStart)) == kBaseValid);
+			cnt -= ((en & (kBaseValid | kBaseStart)) == kBaseValid);
+			first_valid = (en >> 3) & 1;
+		}
+		const bool ok = first_valid && cnt == k - 1;
+		WinHash<SPACED> wh;
+		wh.kms = hp.kms;
+		wh.stn = 0;
+		wh.bcan = rh < fh ? rh : fh;
+		if (SPACED) {
+			const uint32_t h2 = hp.h2;
+			for (uint32_t j = 0; j < hp.n_seeds; ++j) {
+				uint64_t fs = fh, rs = rh;
+				for (uint32_t d = hp.dc_off[j]; d < hp.dc_off[j + 1]; ++d) {
+					const uint32_t i = dc_idx[d];
+					const U64x2 tt = pos_tab[i * kNumCodes + (tile[li0 + w + i] & kCodeMask)];
+					fs ^= tt.x;
+					rs ^= tt.y;
+				}
+				const bool s = rs < fs;
+				const uint64_t b = s ? rs : fs;
+				wh.hv[SPACED ? j * h2 : 0] = b;
+				for (uint32_t j2 = 1; j2 < h2; ++j2)
+					wh.hv[SPACED ? j * h2 + j2 : 0] = extra_hash(b, hp.kms, j2);
+				if (s)
+					for (uint32_t j2 = 0; j2 < h2; ++j2)
+						wh.stn |= 1u << (j * h2 + j2); // h <= 32 here
+			}
+		}
+		f(w, ok, wh);
+	}
+}
+
+// advance "offset of the tile start inside its read" by one tile (uniform layout)
+__device__ __forceinline__ uint32_t seq_next_tile_off(uint32_t tile_off, uint32_t tile_step, uint32_t L)
+{
+	tile_off += tile_step;
+	if (L && tile_off >= L)
+		tile_off -= L;
+	return tile_off;
+}
+
+} // namespace btlbf

@@ -116,6 +116,16 @@ int btlbf_clear(btlbf_filter* f, void* stream);
 int btlbf_upload(btlbf_filter* f, const void* host_src, uint64_t offset, uint64_t nbytes);
 int btlbf_download(const btlbf_filter* f, void* host_dst, uint64_t offset, uint64_t nbytes);
 
+/* How btlbf_insert_seqs applies a batch to a bit filter.  DIRECT: one atomicOr per probe (random HBM
+ * access).  PARTITIONED: probe positions are radix-partitioned by filter segment and ORed into the
+ * segment while it sits in LDS (streamed HBM access; needs scratch memory, pays one sweep of the
+ * array per batch).  AUTO picks PARTITIONED when the batch is large relative to the filter.  The
+ * filter bytes are identical either way (bit OR is order-free).  scratch_bytes caps the scratch
+ * allocation (0 = up to 80 % of the free HBM).  Default: BTLBF_INSERT_AUTO, or the environment
+ * variable BTLBF_INSERT_MODE=direct|partitioned. */
+enum { BTLBF_INSERT_AUTO = 0, BTLBF_INSERT_DIRECT = 1, BTLBF_INSERT_PARTITIONED = 2 };
+int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch_bytes);
+
 /* Use spaced-seed hashing (stHashIterator, vendor/stHashIterator.hpp:23-33,53-57) for every
  * sequence-buffer call on this filter: `seeds` are n_seeds strings of length kmer_size, '1' =
  * care; hash_num must equal n_seeds*h2.  Without this call sequences are hashed like

@@ -428,3 +428,92 @@ def test_full_size_filter_properties(bf):
     q = bf.synth_reads_device(43, 0, n, L)
     _, _, cnt = flt.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
     assert cnt[0].item() == n * 120 and cnt[1].item() < 10
+
+
+# ---------------------------------------------------------------------------------------------
+# partitioned insert (radix partition by segment + LDS apply): same bytes as the direct kernel
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["bf_small", "bf_nonpow2", "bf_medium", "bf_config1"])
+def test_partitioned_insert_golden_digests(bf, name):
+    g = load_golden("digests.json")[name]  # 1-level (small, nonpow2) and 2-level (medium, config1) geometries
+    flt = bf.BloomFilter(g["bits"], g["h"], g["k"])
+    flt.setInsertMode("partitioned")
+    reads = bf.synth_reads_device(g["seed"], 0, g["n_reads"], g["read_len"])
+    flt.insertSeqs(reads, read_len=g["read_len"])
+    assert flt.getPop() == g["pop"]
+    assert hashlib.sha256(flt.download().tobytes()).hexdigest() == g["body_sha256"]
+
+
+@pytest.mark.parametrize("bits,k,h", [(1000, 5, 4), (1 << 19, 31, 1), ((1 << 19) + 64, 31, 3), (3 << 29, 25, 5),
+                                      (1 << 31, 64, 2)])
+def test_partitioned_equals_direct_odd_shapes(bf, oracle, bits, k, h):
+    import torch
+
+    rng = np.random.RandomState(bits % 977 + k)
+    lens = [int(x) for x in rng.randint(0, 400, 300)] + [5000, 0, k, k - 1]
+    reads = [rand_seq(rng, n, 0.01) for n in lens]
+    buf = b"".join(reads)
+    starts = np.cumsum([0] + lens).astype(np.uint64)
+    a, b = bf.BloomFilter(bits, h, k), bf.BloomFilter(bits, h, k)
+    a.setInsertMode("direct")
+    b.setInsertMode("partitioned")
+    # ragged layout on a deliberately misaligned device pointer
+    t = torch.zeros(len(buf) + 16, dtype=torch.uint8, device="cuda")
+    t[3:3 + len(buf)] = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+    ts = torch.from_numpy(starts.astype(np.int64)).cuda()
+    a.insertSeqs(t[3:3 + len(buf)], starts=ts)
+    b.insertSeqs(t[3:3 + len(buf)], starts=ts)
+    torch.cuda.synchronize()
+    assert a.getPop() == b.getPop() > 0
+    if bits <= 1 << 24:
+        mine = np.zeros(bits // 8, np.uint8)
+        for r in reads:
+            oracle.bf_insert_seq(mine, bits, h, k, r)
+        assert (b.download() == mine).all()
+    else:
+        assert hashlib.sha256(a.download()).hexdigest() == hashlib.sha256(b.download()).hexdigest()
+
+
+def test_partitioned_small_scratch_many_batches_and_skew(bf):
+    """a scratch cap forces several batches; 4000 copies of one read overflow their bins, which must
+    fall back to direct atomics instead of dropping entries"""
+    import torch
+
+    bits, h, k, L = 1 << 30, 4, 31, 150
+    reads = bf.synth_reads_device(42, 0, 60000, L)
+    skew = reads[:L].repeat(4000)
+    buf = torch.cat([reads, skew, reads[: 1000 * L]])
+    a, b = bf.BloomFilter(bits, h, k), bf.BloomFilter(bits, h, k)
+    a.setInsertMode("direct")
+    b.setInsertMode("partitioned", scratch_bytes=48 << 20)
+    a.insertSeqs(buf, read_len=L)
+    b.insertSeqs(buf, read_len=L)
+    torch.cuda.synchronize()
+    assert a.getPop() == b.getPop()
+    assert hashlib.sha256(a.download()).hexdigest() == hashlib.sha256(b.download()).hexdigest()
+
+
+def test_partitioned_spaced_seeds_and_shard(bf):
+    import torch
+
+    seeds = ["1110111011101110111011101110111", "1101101101101101011011011011011",
+             "1111001111001111111001111001111", "1011101011101011101011101011101"]
+    bits, L = 1 << 30, 150
+    reads = bf.synth_reads_device(7, 0, 30000, L)
+    a, b = bf.BloomFilter(bits, 4, 31), bf.BloomFilter(bits, 4, 31)
+    for f, mode in ((a, "direct"), (b, "partitioned")):
+        f.setSpacedSeeds(seeds, 1)
+        f.setInsertMode(mode)
+        f.insertSeqs(reads, read_len=L)
+    torch.cuda.synchronize()
+    assert (a.download() == b.download()).all()
+    # a shard only keeps the positions it owns, in either mode
+    whole = bf.BloomFilter(bits, 4, 31)
+    whole.insertSeqs(reads, read_len=L)
+    body = whole.download()
+    for idx in (0, 3):
+        s = bf.BloomFilter.shard(bits, idx, 4, 4, 31)
+        s.setInsertMode("partitioned")
+        s.insertSeqs(reads, read_len=L)
+        n = bits // 8 // 4
+        assert (s.download() == body[idx * n:(idx + 1) * n]).all()
