@@ -859,6 +859,8 @@ struct PartPlan {
 	uint64_t bytes_cur0, bytes_cur1, bytes_out0, bytes_out1, bytes_total;
 };
 
+// chunks a region needs for `mean_entries` expected entries (Poisson: mean + 8 sigma) plus the
+// partially filled chunks flushed at kernel end
 uint32_t chunks_for(double mean_entries, uint32_t tail_chunks)
 {
 	const double m = mean_entries + 8.0 * std::sqrt(mean_entries + 1.0) + 32.0;
@@ -877,19 +879,32 @@ bool plan_partition(const btlbf_filter* f, uint64_t total_tiles, double probes_p
 	pa.n_seg = (mloc + (1ull << pa.seg_shift) - 1) >> pa.seg_shift;
 	if (pa.n_seg > 1024ull * 1024)
 		return false;
-	pa.levels = pa.n_seg <= 1024 ? 1 : 2;
-	pa.p1 = pa.levels == 2 ? 1024 : 1;
-	pa.p0 = (uint32_t)(pa.levels == 2 ? (pa.n_seg + 1023) / 1024 : pa.n_seg);
-	pa.bin_shift = pa.seg_shift + (pa.levels == 2 ? 10 : 0);
+	if (pa.n_seg <= 1024) {
+		pa.levels = 1;
+		pa.p0 = (uint32_t)pa.n_seg;
+		pa.p1 = 1;
+		pa.bin_shift = pa.seg_shift;
+	} else { // split the segment index bits evenly between the two levels
+		unsigned bits = 0;
+		while ((1ull << bits) < pa.n_seg)
+			++bits;
+		const unsigned b1 = bits / 2;
+		pa.levels = 2;
+		pa.p1 = 1u << b1;
+		pa.p0 = (uint32_t)((pa.n_seg + pa.p1 - 1) >> b1);
+		pa.bin_shift = pa.seg_shift + b1;
+	}
+	pa.regions0 = blocks_a;
+	pa.regions1 = pa.levels == 2 ? std::max(1u, std::min(blocks_a, (512 + pa.p0 - 1) / pa.p0)) : 0;
 	uint64_t tiles = total_tiles;
 	for (int iter = 0; iter < 64; ++iter) {
 		const double nb = (double)tiles * probes_per_tile;
-		pa.cap0 = chunks_for(nb / pa.p0, blocks_a + 1);
-		pa.cap1 = pa.levels == 2 ? chunks_for(nb / (double)pa.n_seg, 2) : 0;
-		pl.bytes_cur0 = ((uint64_t)pa.p0 * 4 + 255) / 256 * 256;
-		pl.bytes_cur1 = pa.levels == 2 ? (uint64_t)pa.p0 * pa.p1 * 4 : 0;
-		pl.bytes_out0 = (uint64_t)pa.p0 * pa.cap0 * 128;
-		pl.bytes_out1 = pa.levels == 2 ? (uint64_t)pa.p0 * pa.p1 * pa.cap1 * 128 : 0;
+		pa.cap0 = chunks_for(nb / ((double)pa.p0 * pa.regions0), 1);
+		pa.cap1 = pa.levels == 2 ? chunks_for(nb / ((double)pa.p0 * pa.p1 * pa.regions1), 1) : 0;
+		pl.bytes_cur0 = ((uint64_t)pa.p0 * pa.regions0 * 4 + 255) / 256 * 256;
+		pl.bytes_cur1 = pa.levels == 2 ? ((uint64_t)pa.p0 * pa.p1 * pa.regions1 * 4 + 255) / 256 * 256 : 0;
+		pl.bytes_out0 = (uint64_t)pa.p0 * pa.regions0 * pa.cap0 * 128;
+		pl.bytes_out1 = pa.levels == 2 ? (uint64_t)pa.p0 * pa.p1 * pa.regions1 * pa.cap1 * 128 : 0;
 		pl.bytes_total = pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0 + pl.bytes_out1;
 		if (pl.bytes_total <= budget || tiles <= 1)
 			break;
@@ -961,8 +976,8 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 		SeqArgs a = base;
 		a.first_tile = t0;
 		a.n_tiles = std::min<uint64_t>(pl.tiles_per_batch, total_tiles - t0);
-		HIP_TRY(hipMemsetAsync(p, 0, pl.bytes_cur0 + pl.bytes_cur1, s));
-		HIP_TRY(launch_part_hash(a, pl.pa, blocks_a, s));
+		HIP_TRY(launch_part_hash(a, pl.pa, s)); // every writer publishes all of its region counts
+
 		if (pl.pa.levels == 2)
 			HIP_TRY(launch_part_split(f->d_data, pl.pa, s));
 		HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, s));

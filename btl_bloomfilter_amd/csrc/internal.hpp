@@ -121,21 +121,24 @@ struct SeqArgs {
 struct PartArgs {
 	uint32_t levels;    // 1: pass A bins are segments; 2: pass A bins hold p1 segments each
 	uint32_t seg_shift; // log2(bits per segment)
-	uint32_t bin_shift; // log2(bits per level-0 bin) = seg_shift (+10 when levels == 2)
-	uint32_t p0, p1;    // level-0 bins (<= 1024), sub-bins per level-0 bin (1024 when levels == 2)
+	uint32_t bin_shift; // log2(bits per level-0 bin) = seg_shift + log2(p1)
+	uint32_t p0, p1;    // level-0 bins (<= 1024); sub-bins per level-0 bin (power of two <= 1024)
 	uint64_t n_seg;
-	uint32_t cap0, cap1; // capacity of a level-0 bin / a sub-bin, in 32-entry chunks
-	uint32_t* cur0;      // [p0] chunk cursors
-	uint32_t* cur1;      // [p0*p1]
-	uint32_t* out0;      // [p0][cap0][32]
-	uint32_t* out1;      // [p0*p1][cap1][32]
+	// every bin is written by several workgroups, each into its own REGION of cap chunks:
+	// region index = bin * regions + writer
+	uint32_t regions0, regions1; // writers per level-0 bin (= pass-A workgroups) / per sub-bin
+	uint32_t cap0, cap1;         // region capacity in 32-entry chunks
+	uint32_t* cur0;              // [p0*regions0] chunks written per region
+	uint32_t* cur1;              // [p0*p1*regions1]
+	uint32_t* out0;              // [p0*regions0][cap0][32]
+	uint32_t* out1;              // [p0*p1*regions1][cap1][32]
 };
 
 // launchers (defined in the .hip files)
 int part_tile_windows();
 bool part_supported_h(uint32_t h);
 uint32_t part_hash_lds_bytes(const HashParams& hp, uint32_t p0);
-hipError_t launch_part_hash(const SeqArgs& a, const PartArgs& pa, unsigned blocks, hipStream_t s);
+hipError_t launch_part_hash(const SeqArgs& a, const PartArgs& pa, hipStream_t s);
 hipError_t launch_part_split(void* filter, const PartArgs& pa, hipStream_t s);
 hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs& pa, hipStream_t s);
 hipError_t launch_seq_op(int op, const SeqArgs& a, hipStream_t s);

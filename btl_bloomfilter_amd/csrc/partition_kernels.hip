@@ -7,17 +7,19 @@
 // SEGMENT they fall into, with that segment held in LDS.  The result is bit-identical.
 //
 //   pass A  part_hash_kernel   fused ntHash (seq_core.hpp) + radix partition of the local positions
-//                              by their top bits into <= 1024 level-0 bins
+//                              by their top bits into p0 <= 1024 level-0 bins
 //   pass B  part_split_kernel  (filters with more than 1024 segments) splits every level-0 bin into
-//                              <= 1024 sub-bins = segments
+//                              p1 <= 1024 sub-bins = segments
 //   pass C  part_apply_kernel  one workgroup per segment: load the segment into LDS, ds_or every
 //                              entry, store the segment back
 //
-// Bins are arrays of 128-byte CHUNKS (32 uint32 entries).  A workgroup stages entries per bin in LDS
-// and writes a chunk only when it is full, so every global write is one aligned 128-byte line and
-// costs one atomicAdd on the bin's chunk cursor per 32 entries; chunks flushed at kernel end are
-// padded with a sentinel.  Entries that do not fit (a bin over capacity, or more than two chunks of
-// one bin inside one round) are applied to the filter directly with atomicOr -- never dropped.
+// Bins are written as 128-byte CHUNKS (32 uint32 entries).  A workgroup stages entries per bin in an
+// LDS ring and writes a chunk only when it is full, so every global write is one aligned 128-byte
+// line.  Every workgroup writes into its OWN region of every bin (region = (bin, writer)), so chunk
+// slots are handed out from an LDS counter: no global atomics anywhere in passes A and B.  Chunks
+// flushed at kernel end are padded with a sentinel.  Entries that do not fit (a region over capacity,
+// or a bin that receives more than about two rings' worth inside one round) are applied to the
+// filter directly with atomicOr -- never dropped.
 #include "seq_core.hpp"
 
 namespace btlbf {
@@ -26,30 +28,49 @@ static constexpr int kPartThreads = 512;
 static constexpr int kPartTile = kPartThreads * kW; // windows per round of pass A
 static constexpr uint32_t kChunk = 32;              // entries per chunk
 static constexpr uint32_t kSentinel = 0xffffffffu;
-static constexpr uint32_t kMaxBins = 1024;
+static constexpr uint32_t kStageEntries = 32768;    // LDS staging: 128 KiB of uint32 entries
 
 // LDS image of the staged partitioner (carved from dynamic LDS by the kernels)
 struct PartLds {
-	uint32_t* stage; // [P][32]
-	uint32_t* fill;  // [P] entries currently staged (0..32)
-	uint32_t* hist;  // [P] per-round counts, then totals
-	uint16_t* flist; // [P] bins to flush this round
+	uint32_t* stage;   // [P][SC] ring per bin, SC = kStageEntries / pow2ceil(P)
+	uint32_t* head;    // [P] ring read position (multiple of 32, grows forever)
+	uint32_t* tail;    // [P] ring write position
+	uint32_t* hist;    // [P] per-round counts, then tail+count totals
+	uint32_t* written; // [P] chunks written to this workgroup's region of the bin
+	uint32_t* fout;    // [1024] output chunk index of each flush item
+	uint16_t* flist;   // [1024] flush items: bin | ring chunk << 10
 	uint32_t* fcount;
+	uint32_t sc_shift; // log2(SC)
 };
+
+__host__ __device__ inline uint32_t part_pow2ceil(uint32_t x)
+{
+	uint32_t p = 1;
+	while (p < x)
+		p <<= 1;
+	return p;
+}
 
 __host__ __device__ inline uint32_t part_lds_bytes(uint32_t P)
 {
-	return P * kChunk * 4 + P * 4 + P * 4 + ((P * 2 + 15) / 16) * 16 + 16;
+	return kStageEntries * 4 + 4 * P * 4 + 1024 * 4 + 1024 * 2 + 16;
 }
 
 __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
 {
 	PartLds l;
 	l.stage = reinterpret_cast<uint32_t*>(base);
-	l.fill = l.stage + P * kChunk;
-	l.hist = l.fill + P;
-	l.flist = reinterpret_cast<uint16_t*>(l.hist + P);
-	l.fcount = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l.flist) + ((P * 2 + 15) / 16) * 16);
+	l.head = l.stage + kStageEntries;
+	l.tail = l.head + P;
+	l.hist = l.tail + P;
+	l.written = l.hist + P;
+	l.fout = l.written + P;
+	l.flist = reinterpret_cast<uint16_t*>(l.fout + 1024);
+	l.fcount = reinterpret_cast<uint32_t*>(l.flist + 1024);
+	uint32_t pc = part_pow2ceil(P < 32 ? 32 : P), sh = 0;
+	while ((kStageEntries >> sh) > pc)
+		++sh; // kStageEntries / 2^sh == pc  ->  SC = 2^sh
+	l.sc_shift = sh;
 	return l;
 }
 
@@ -57,8 +78,10 @@ template <int NT>
 __device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
 {
 	for (uint32_t b = threadIdx.x; b < P; b += NT) {
-		l.fill[b] = 0;
+		l.head[b] = 0;
+		l.tail[b] = 0;
 		l.hist[b] = 0;
+		l.written[b] = 0;
 	}
 	if (threadIdx.x == 0)
 		*l.fcount = 0;
@@ -66,34 +89,53 @@ __device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
 
 // One round: every thread contributes E entries (bin[e] == kSentinel marks an empty slot).
 // Precondition: hist[] all zero, fcount zero, and a barrier since they were written.
+// Region r of bin b starts at out + ((uint64_t)b * n_regions + r) * cap_chunks * 32.
 // `ovf(bin, val)` must apply the entry to the filter directly.
 template <int NT, int E, class OVF>
 __device__ __forceinline__ void part_round(const PartLds& l, uint32_t P, const uint32_t (&bin)[E],
-                                           const uint32_t (&val)[E], uint32_t* cursors, uint32_t* out,
-                                           uint32_t cap_chunks, OVF&& ovf)
+                                           const uint32_t (&val)[E], uint32_t* out, uint32_t n_regions,
+                                           uint32_t region, uint32_t cap_chunks, OVF&& ovf)
 {
 	const uint32_t tid = threadIdx.x;
-	uint32_t idx[E];
+	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
+	uint32_t pos[E];
+	uint64_t staged = 0; // bit e: entry e found room in the ring before this round's flush
+	static_assert(E <= 64, "one flag bit per entry");
 	// rank inside the bin for this round
 #pragma unroll
 	for (int e = 0; e < E; ++e)
-		idx[e] = bin[e] != kSentinel ? atomicAdd(&l.hist[bin[e]], 1u) : 0;
+		pos[e] = bin[e] != kSentinel ? atomicAdd(&l.hist[bin[e]], 1u) : 0;
 	__syncthreads();
-	// absolute slot = entries already staged + rank; slots < 32 go into the open chunk
+	// absolute position in the bin's stream; positions inside the ring window are staged now
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
 		if (bin[e] != kSentinel) {
-			idx[e] += l.fill[bin[e]];
-			if (idx[e] < kChunk)
-				l.stage[bin[e] * kChunk + idx[e]] = val[e];
+			pos[e] += l.tail[bin[e]];
+			if (pos[e] - l.head[bin[e]] < SC) {
+				l.stage[(bin[e] << l.sc_shift) + (pos[e] & ring)] = val[e];
+				staged |= 1ull << e;
+			}
 		}
 	}
 	__syncthreads();
+	// per bin: how many full chunks can leave; reserve their output slots in this workgroup's region
 	for (uint32_t b = tid; b < P; b += NT) {
-		const uint32_t tot = l.fill[b] + l.hist[b];
+		const uint32_t hd = l.head[b];
+		const uint32_t tot = l.tail[b] + l.hist[b];
+		const uint32_t lm = hd + SC;
+		const uint32_t avail = (int32_t)(tot - lm) < 0 ? tot : lm;
+		const uint32_t nfl = (avail - hd) >> 5;
 		l.hist[b] = tot;
-		if (tot >= kChunk)
-			l.flist[atomicAdd(l.fcount, 1u)] = (uint16_t)b;
+		if (nfl) {
+			const uint32_t base = atomicAdd(l.fcount, nfl);
+			const uint32_t w0 = l.written[b];
+			for (uint32_t c = 0; c < nfl; ++c) {
+				l.flist[base + c] = (uint16_t)(b | ((((hd >> 5) + c) & (ring >> 5)) << 10));
+				l.fout[base + c] = w0 + c;
+			}
+			l.written[b] = w0 + nfl;
+			l.head[b] = hd + (nfl << 5);
+		}
 	}
 	__syncthreads();
 	// flush full chunks: one half-wave (32 lanes) per chunk, one aligned 128-byte store
@@ -101,66 +143,63 @@ __device__ __forceinline__ void part_round(const PartLds& l, uint32_t P, const u
 		const uint32_t n = *l.fcount;
 		const uint32_t lane32 = tid & 31;
 		for (uint32_t j = tid >> 5; j < n; j += NT / 32) {
-			const uint32_t b = l.flist[j];
-			const uint32_t v = l.stage[b * kChunk + lane32];
-			uint32_t chunk = 0;
-			if (lane32 == 0)
-				chunk = atomicAdd(&cursors[b], 1u);
-			chunk = __shfl(chunk, tid & 32, 64);
-			if (chunk < cap_chunks)
-				out[((uint64_t)b * cap_chunks + chunk) * kChunk + lane32] = v;
+			const uint32_t it = l.flist[j];
+			const uint32_t b = it & 1023, rc = it >> 10, oc = l.fout[j];
+			const uint32_t v = l.stage[(b << l.sc_shift) + (rc << 5) + lane32];
+			if (oc < cap_chunks)
+				out[(((uint64_t)b * n_regions + region) * cap_chunks + oc) * kChunk + lane32] = v;
 			else
 				ovf(b, v);
 		}
 	}
 	__syncthreads();
-	// second chunk's worth goes into the emptied buffer; anything beyond is applied directly
+	// entries that did not fit before the flush: into the freed ring space, else applied directly
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
-		if (bin[e] != kSentinel && idx[e] >= kChunk) {
-			const uint32_t i2 = idx[e] - kChunk;
-			if (i2 < kChunk)
-				l.stage[bin[e] * kChunk + i2] = val[e];
+		if (bin[e] != kSentinel && !((staged >> e) & 1)) {
+			if (pos[e] - l.head[bin[e]] < SC)
+				l.stage[(bin[e] << l.sc_shift) + (pos[e] & ring)] = val[e];
 			else
 				ovf(bin[e], val[e]);
 		}
 	}
-	__syncthreads();
 	for (uint32_t b = tid; b < P; b += NT) {
-		const uint32_t tot = l.hist[b];
-		l.fill[b] = tot >= kChunk ? (tot - kChunk < kChunk ? tot - kChunk : kChunk) : tot;
+		const uint32_t tot = l.hist[b], lm = l.head[b] + SC;
+		l.tail[b] = (int32_t)(tot - lm) < 0 ? tot : lm; // entries beyond went to the filter directly
 		l.hist[b] = 0;
 	}
 	if (tid == 0)
 		*l.fcount = 0;
-	// the caller's next barrier (tile staging / loop top) orders these writes before the next round
+	// the caller's next barrier orders these writes before the next round
 }
 
-// flush whatever is staged, padded with the sentinel
+// flush whatever is staged (padded with the sentinel) and publish the chunk counts of this region
 template <int NT, class OVF>
-__device__ __forceinline__ void part_finish(const PartLds& l, uint32_t P, uint32_t* cursors, uint32_t* out,
-                                            uint32_t cap_chunks, OVF&& ovf)
+__device__ __forceinline__ void part_finish(const PartLds& l, uint32_t P, uint32_t* out, uint32_t* counts,
+                                            uint32_t n_regions, uint32_t region, uint32_t cap_chunks, OVF&& ovf)
 {
 	__syncthreads();
 	const uint32_t tid = threadIdx.x, lane32 = tid & 31;
+	const uint32_t ring = (1u << l.sc_shift) - 1;
 	for (uint32_t b = tid >> 5; b < P; b += NT / 32) {
-		const uint32_t n = l.fill[b];
-		if (n == 0)
-			continue;
-		const uint32_t v = lane32 < n ? l.stage[b * kChunk + lane32] : kSentinel;
-		uint32_t chunk = 0;
+		const uint32_t hd = l.head[b], n = l.tail[b] - hd;
+		uint32_t oc = l.written[b];
+		for (uint32_t c = 0; c * kChunk < n; ++c, ++oc) {
+			const uint32_t i = c * kChunk + lane32;
+			const uint32_t v = i < n ? l.stage[(b << l.sc_shift) + ((hd + i) & ring)] : kSentinel;
+			if (oc < cap_chunks)
+				out[(((uint64_t)b * n_regions + region) * cap_chunks + oc) * kChunk + lane32] = v;
+			else if (v != kSentinel)
+				ovf(b, v);
+		}
 		if (lane32 == 0)
-			chunk = atomicAdd(&cursors[b], 1u);
-		chunk = __shfl(chunk, tid & 32, 64);
-		if (chunk < cap_chunks)
-			out[((uint64_t)b * cap_chunks + chunk) * kChunk + lane32] = v;
-		else if (v != kSentinel)
-			ovf(b, v);
+			counts[(uint64_t)b * n_regions + region] = oc < cap_chunks ? oc : cap_chunks;
 	}
 }
 
 // ---- pass A --------------------------------------------------------------------------------------
 // bin = local_position >> bin_shift ; entry = local_position & ((1 << bin_shift) - 1)
+// region = blockIdx.x (gridDim.x == pa.regions0)
 template <int H, bool POW2, bool SPACED>
 __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a, const PartArgs pa)
 {
@@ -177,7 +216,7 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 
 	uint32_t* words = static_cast<uint32_t*>(a.filter);
 	const uint32_t bin_shift = pa.bin_shift;
-	const uint32_t ent_mask = (1u << bin_shift) - 1;
+	const uint32_t ent_mask = (uint32_t)((1ull << bin_shift) - 1);
 	auto ovf = [&](uint32_t b, uint32_t v) { bf_set(words, ((uint64_t)b << bin_shift) | v); };
 
 	const uint64_t t_begin = a.first_tile + (uint64_t)blockIdx.x * a.tiles_per_block;
@@ -205,18 +244,20 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 				val[w * H + i] = (uint32_t)p & ent_mask;
 			}
 		});
-		part_round<kPartThreads, kW * H>(pl, pa.p0, bin, val, pa.cur0, pa.out0, pa.cap0, ovf);
+		part_round<kPartThreads, kW * H>(pl, pa.p0, bin, val, pa.out0, pa.regions0, blockIdx.x, pa.cap0, ovf);
 	}
-	part_finish<kPartThreads>(pl, pa.p0, pa.cur0, pa.out0, pa.cap0, ovf);
+	part_finish<kPartThreads>(pl, pa.p0, pa.out0, pa.cur0, pa.regions0, blockIdx.x, pa.cap0, ovf);
 }
 
 // ---- pass B --------------------------------------------------------------------------------------
-// one workgroup per level-0 bin: entry e -> sub-bin e >> seg_shift, new entry e & seg_mask
+// workgroup (b0, g): blockIdx.x = b0 * regions1 + g.  It consumes pass-A regions g, g+regions1, ...
+// of level-0 bin b0 and writes region g of every sub-bin of b0.
+// entry e -> sub-bin e >> seg_shift, new entry e & seg_mask.
 __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, const PartArgs pa)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	const uint32_t tid = threadIdx.x;
-	const uint32_t b0 = blockIdx.x;
+	const uint32_t b0 = blockIdx.x / pa.regions1, g = blockIdx.x % pa.regions1;
 	const PartLds pl = part_carve(dyn, pa.p1);
 	part_init<kPartThreads>(pl, pa.p1);
 	uint32_t* words = static_cast<uint32_t*>(filter);
@@ -225,51 +266,66 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 	const uint64_t bin_base = (uint64_t)b0 << pa.bin_shift;
 	auto ovf = [&](uint32_t sub, uint32_t v) { bf_set(words, bin_base | ((uint64_t)sub << seg_shift) | v); };
 
-	uint32_t n_chunks = pa.cur0[b0];
-	if (n_chunks > pa.cap0)
-		n_chunks = pa.cap0;
-	const uint4* src = reinterpret_cast<const uint4*>(pa.out0 + (uint64_t)b0 * pa.cap0 * kChunk);
-	const uint64_t n_vec = (uint64_t)n_chunks * (kChunk / 4);
-	uint32_t* cur = pa.cur1 + (uint64_t)b0 * pa.p1;
-	uint32_t* out = pa.out1 + (uint64_t)b0 * pa.p1 * pa.cap1 * kChunk;
+	uint32_t* cur = pa.cur1 + (uint64_t)b0 * pa.p1 * pa.regions1;
+	uint32_t* out = pa.out1 + (uint64_t)b0 * pa.p1 * pa.regions1 * pa.cap1 * kChunk;
 	constexpr int kVec = 4; // uint4 loads per thread per round -> 16 entries
 	__syncthreads();
-	for (uint64_t base = 0; base < n_vec; base += (uint64_t)kPartThreads * kVec) {
-		uint32_t bin[kVec * 4], val[kVec * 4];
+	for (uint32_t r = g; r < pa.regions0; r += pa.regions1) {
+		const uint64_t reg = (uint64_t)b0 * pa.regions0 + r;
+		uint32_t n_chunks = pa.cur0[reg];
+		if (n_chunks > pa.cap0)
+			n_chunks = pa.cap0;
+		const uint4* src = reinterpret_cast<const uint4*>(pa.out0 + reg * pa.cap0 * kChunk);
+		const uint32_t n_vec = n_chunks * (kChunk / 4);
+		// software pipeline: the next round's loads are in flight while this round is partitioned
+		uint4 nxt[kVec];
 #pragma unroll
 		for (int v = 0; v < kVec; ++v) {
-			const uint64_t i = base + (uint64_t)v * kPartThreads + tid;
-			uint4 q = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
-			if (i < n_vec)
-				q = src[i];
-			const uint32_t e4[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-			for (int c = 0; c < 4; ++c) {
-				bin[v * 4 + c] = e4[c] == kSentinel ? kSentinel : e4[c] >> seg_shift;
-				val[v * 4 + c] = e4[c] & seg_mask;
-			}
+			const uint32_t i = (uint32_t)v * kPartThreads + tid;
+			nxt[v] = i < n_vec ? src[i] : make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
 		}
-		part_round<kPartThreads, kVec * 4>(pl, pa.p1, bin, val, cur, out, pa.cap1, ovf);
-		__syncthreads();
+		for (uint32_t base = 0; base < n_vec; base += kPartThreads * kVec) {
+			uint32_t bin[kVec * 4], val[kVec * 4];
+#pragma unroll
+			for (int v = 0; v < kVec; ++v) {
+				const uint32_t e4[4] = {nxt[v].x, nxt[v].y, nxt[v].z, nxt[v].w};
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					bin[v * 4 + c] = e4[c] == kSentinel ? kSentinel : e4[c] >> seg_shift;
+					val[v * 4 + c] = e4[c] & seg_mask;
+				}
+				const uint32_t i = base + kPartThreads * kVec + (uint32_t)v * kPartThreads + tid;
+				nxt[v] = i < n_vec ? src[i] : make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
+			}
+			part_round<kPartThreads, kVec * 4>(pl, pa.p1, bin, val, out, pa.regions1, g, pa.cap1, ovf);
+			__syncthreads();
+		}
 	}
-	part_finish<kPartThreads>(pl, pa.p1, cur, out, pa.cap1, ovf);
+	part_finish<kPartThreads>(pl, pa.p1, out, cur, pa.regions1, g, pa.cap1, ovf);
 }
 
 // ---- pass C --------------------------------------------------------------------------------------
-// one workgroup per segment; `cur`/`ent`/`cap` describe the bins that ARE segments (level 1, or
-// level 0 for filters with <= 1024 segments)
+// one workgroup per segment; the segment's entries sit in `n_regions` regions of `cap` chunks each
 __global__ __launch_bounds__(kPartThreads) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
                                                                  uint32_t seg_shift, const uint32_t* cur,
-                                                                 const uint32_t* ent, uint32_t cap)
+                                                                 const uint32_t* ent, uint32_t cap,
+                                                                 uint32_t n_regions)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
+	__shared__ uint32_t any;
 	const uint32_t tid = threadIdx.x;
 	const uint64_t seg = blockIdx.x;
-	uint32_t n_chunks = cur[seg];
-	if (n_chunks == 0)
+	if (tid == 0)
+		any = 0;
+	__syncthreads();
+	uint32_t mine = 0;
+	for (uint32_t r = tid; r < n_regions; r += kPartThreads)
+		mine |= cur[seg * n_regions + r];
+	if (mine)
+		any = 1;
+	__syncthreads();
+	if (!any)
 		return; // untouched segment: no traffic at all
-	if (n_chunks > cap)
-		n_chunks = cap;
 	const uint64_t seg_bytes = 1ull << (seg_shift - 3);
 	const uint64_t byte0 = seg * seg_bytes;
 	uint64_t nbytes = local_bytes - byte0;
@@ -282,15 +338,21 @@ __global__ __launch_bounds__(kPartThreads) void part_apply_kernel(uint8_t* filte
 		lds4[i] = g4[i];
 	__syncthreads();
 	uint32_t* lds = reinterpret_cast<uint32_t*>(dyn);
-	const uint4* e4 = reinterpret_cast<const uint4*>(ent + seg * (uint64_t)cap * kChunk);
-	const uint32_t n_ev = n_chunks * (kChunk / 4);
-	for (uint32_t i = tid; i < n_ev; i += kPartThreads) {
-		const uint4 q = e4[i];
-		const uint32_t e[4] = {q.x, q.y, q.z, q.w};
+	for (uint32_t r = 0; r < n_regions; ++r) {
+		const uint64_t reg = seg * n_regions + r;
+		uint32_t n_chunks = cur[reg];
+		if (n_chunks > cap)
+			n_chunks = cap;
+		const uint4* e4 = reinterpret_cast<const uint4*>(ent + reg * cap * kChunk);
+		const uint32_t n_ev = n_chunks * (kChunk / 4);
+		for (uint32_t i = tid; i < n_ev; i += kPartThreads) {
+			const uint4 q = e4[i];
+			const uint32_t e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-		for (int c = 0; c < 4; ++c)
-			if (e[c] != kSentinel)
-				atomicOr(&lds[e[c] >> 5], 1u << (e[c] & 31));
+			for (int c = 0; c < 4; ++c)
+				if (e[c] != kSentinel)
+					atomicOr(&lds[e[c] >> 5], 1u << (e[c] & 31));
+		}
 	}
 	__syncthreads();
 	for (uint32_t i = tid; i < n_vec; i += kPartThreads)
@@ -331,16 +393,15 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartArgs& pa, unsigned b
 
 bool part_supported_h(uint32_t h) { return h >= 1 && h <= 5; }
 
-// pass A over tiles [a.first_tile, +a.n_tiles) (units: kPartTile windows) with `blocks` workgroups
-hipError_t launch_part_hash(const SeqArgs& a_in, const PartArgs& pa, unsigned blocks, hipStream_t s)
+// pass A over tiles [a.first_tile, +a.n_tiles) (units: kPartTile windows); exactly pa.regions0
+// workgroups are launched (one region each; idle ones still publish empty counts)
+hipError_t launch_part_hash(const SeqArgs& a_in, const PartArgs& pa, hipStream_t s)
 {
 	SeqArgs a = a_in;
 	if (a.n_tiles == 0)
 		return hipSuccess;
-	if (blocks > a.n_tiles)
-		blocks = (unsigned)a.n_tiles;
+	const unsigned blocks = pa.regions0;
 	a.tiles_per_block = (a.n_tiles + blocks - 1) / blocks;
-	blocks = (unsigned)((a.n_tiles + a.tiles_per_block - 1) / a.tiles_per_block);
 	const size_t dyn = part_hash_lds_bytes(a.hp, pa.p0);
 	switch (a.hp.h) {
 	case 1: return launch_hash_h<1>(a, pa, blocks, dyn, s);
@@ -359,7 +420,7 @@ hipError_t launch_part_split(void* filter, const PartArgs& pa, hipStream_t s)
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 	if (e != hipSuccess)
 		return e;
-	hipLaunchKernelGGL(part_split_kernel, dim3(pa.p0), dim3(kPartThreads), dyn, s, filter, pa);
+	hipLaunchKernelGGL(part_split_kernel, dim3(pa.p0 * pa.regions1), dim3(kPartThreads), dyn, s, filter, pa);
 	return hipGetLastError();
 }
 
@@ -373,7 +434,7 @@ hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs&
 	const bool two = pa.levels == 2;
 	hipLaunchKernelGGL(part_apply_kernel, dim3((unsigned)pa.n_seg), dim3(kPartThreads), dyn, s,
 	                   static_cast<uint8_t*>(filter), local_bytes, pa.seg_shift, two ? pa.cur1 : pa.cur0,
-	                   two ? pa.out1 : pa.out0, two ? pa.cap1 : pa.cap0);
+	                   two ? pa.out1 : pa.out0, two ? pa.cap1 : pa.cap0, two ? pa.regions1 : pa.regions0);
 	return hipGetLastError();
 }
 

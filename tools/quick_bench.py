@@ -12,7 +12,9 @@ def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 39
     n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
     k, h, L = 31, 4, 150
+    mode = sys.argv[3] if len(sys.argv) > 3 else "auto"
     f = m.BloomFilter(1 << lg, h, k)
+    f.setInsertMode(mode)
     reads = m.synth_reads_device(42, 0, n_reads, L)
     q = m.synth_reads_device(43, 0, n_reads, L)
     torch.cuda.synchronize()
@@ -30,7 +32,7 @@ def main():
         ev[3].record()
         torch.cuda.synchronize()
         ti, th, tm = ev[0].elapsed_time(ev[1]) / 1e3, ev[1].elapsed_time(ev[2]) / 1e3, ev[2].elapsed_time(ev[3]) / 1e3
-        print(json.dumps({"log2_bits": lg, "reads": n_reads, "insert_Gkmers_s": kmers / ti / 1e9,
+        print(json.dumps({"mode": mode, "log2_bits": lg, "reads": n_reads, "insert_Gkmers_s": kmers / ti / 1e9,
                           "query_hit_Gkmers_s": kmers / th / 1e9, "query_miss_Gkmers_s": kmers / tm / 1e9,
                           "hits": c1.tolist(), "miss": c2.tolist()}), flush=True)
 
