@@ -142,6 +142,7 @@ void fill_hash_params(HashParams& hp, unsigned k, unsigned h)
 	hp.k = k;
 	hp.h = h;
 	hp.kms = (uint64_t)k * kMultiSeed;
+	hp.use_pos_tab = k <= 128; // 128*k bytes of LDS; launchers may clear it when LDS is tight
 	for (unsigned c = 0; c < kNumCodes; ++c) {
 		const uint64_t s = fwd_seed(c), rc = rev_seed(c);
 		hp.init_tab[c][0] = s;
@@ -174,21 +175,14 @@ int build_spaced(HashParams& hp, const char* const* seeds, unsigned n_seeds, uns
 				dc.push_back((uint16_t)i);
 	}
 	hp.dc_off[n_seeds] = (uint32_t)dc.size();
-	std::vector<uint64_t> pos((size_t)k * kNumCodes * 2);
-	for (unsigned i = 0; i < k; ++i)
-		for (unsigned c = 0; c < kNumCodes; ++c) {
-			pos[((size_t)i * kNumCodes + c) * 2 + 0] = srol_n(fwd_seed(c), k - 1 - i);
-			pos[((size_t)i * kNumCodes + c) * 2 + 1] = srol_n(rev_seed(c), i);
-		}
-	HIP_TRY(hipMalloc((void**)d_pos, pos.size() * 8));
-	HIP_TRY(hipMemcpy(*d_pos, pos.data(), pos.size() * 8, hipMemcpyHostToDevice));
+	*d_pos = nullptr;
 	HIP_TRY(hipMalloc((void**)d_dc, dc.size() * 2 + 16));
 	if (!dc.empty())
 		HIP_TRY(hipMemcpy(*d_dc, dc.data(), dc.size() * 2, hipMemcpyHostToDevice));
 	hp.n_seeds = n_seeds;
 	hp.h2 = h2;
 	hp.h = n_seeds * h2;
-	hp.pos_tab = *d_pos;
+	hp.use_pos_tab = 1; // spaced seeds are masked through the positional table (k <= 1024 checked above)
 	hp.dc_idx = *d_dc;
 	return BTLBF_OK;
 }
@@ -954,7 +948,7 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 	PartPlan pl;
 	if (!plan_partition(f, total_tiles, probes_per_tile, blocks_a, budget, pl))
 		return BTLBF_OK; // not applicable: caller falls back to the direct kernel
-	if (part_hash_lds_bytes(f->hp, pl.pa.p0) > 160 * 1024)
+	if (!part_hash_fits(f->hp, pl.pa.p0))
 		return BTLBF_OK;
 	if (pl.bytes_total > f->part_bytes) {
 		(void)hipFree(f->d_part);

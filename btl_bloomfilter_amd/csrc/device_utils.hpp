@@ -6,15 +6,35 @@ namespace btlbf {
 
 // One step of ntHash's split rotate: the low 33 bits and the high 31 bits of x each rotate left
 // by one (reference semantics: rol1 + swapbits033, vendor/nthash.hpp:350-352,377-380).
+// Written on the 32-bit halves (hi:lo): lo' = lo<<1 | hi[0];  hi' = hi[30:1]<<2 | hi[31]<<1 | lo[31].
 __device__ __forceinline__ uint64_t srol1(uint64_t x)
 {
-	return ((x << 1) & ~((1ULL << 33) | 1ULL)) | ((x >> 32) & 1ULL) | ((x >> 30) & (1ULL << 33));
+	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+	const uint32_t nlo = (lo << 1) | (hi & 1u);
+	const uint32_t nhi = ((hi << 1) & 0xfffffffcu) | ((hi >> 30) & 2u) | (lo >> 31);
+	return ((uint64_t)nhi << 32) | nlo;
 }
 
 // Inverse step (ror1 + swapbits3263, vendor/nthash.hpp:361-363,383-386).
+// lo' = lo>>1 | hi[0]<<31;  hi' = hi[31:2]<<1 | hi[1]<<31 | lo[0]
 __device__ __forceinline__ uint64_t sror1(uint64_t x)
 {
-	return ((x >> 1) & ~(1ULL << 32)) | ((x & 1ULL) << 32) | ((x & (1ULL << 33)) << 30);
+	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+	const uint32_t nlo = (lo >> 1) | (hi << 31);
+	const uint32_t nhi = ((hi >> 1) & 0x7ffffffeu) | ((hi & 2u) << 30) | (lo & 1u);
+	return ((uint64_t)nhi << 32) | nlo;
+}
+
+// srol applied s times (used once per workgroup to build the positional seed table)
+__device__ __forceinline__ uint64_t srol_n(uint64_t x, uint32_t s)
+{
+	uint64_t lo = x & 0x1FFFFFFFFULL, hi = x >> 33;
+	const uint32_t a = s % 33, b = s % 31;
+	if (a)
+		lo = ((lo << a) | (lo >> (33 - a))) & 0x1FFFFFFFFULL;
+	if (b)
+		hi = ((hi << b) | (hi >> (31 - b))) & 0x7FFFFFFFULL;
+	return (hi << 33) | lo;
 }
 
 // i-th extra hash of a canonical base hash (NTE64, vendor/nthash.hpp:537-542)

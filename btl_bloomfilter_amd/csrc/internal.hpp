@@ -44,6 +44,8 @@ struct HashParams {
 	uint32_t h;        // hashes per window as seen by the filter (n_seeds*h2 when spaced)
 	uint32_t n_seeds;  // 0 = plain ntHash (ntHashIterator); >0 = spaced seeds (stHashIterator)
 	uint32_t h2;
+	uint32_t use_pos_tab; // build pos_tab[i*8+c] = {srol^(k-1-i)(fwd[c]), srol^i(rev[c])} in LDS (k small enough)
+	uint32_t pad_;
 	uint64_t kms;      // k * multiSeed (nthash.hpp:585-589: multiplier is i ^ (k*multiSeed))
 	// per code c: {fwd[c], srol^(k-1)(rev[c])}                 -> Horner start-up of fh / rh
 	uint64_t init_tab[8][2];
@@ -51,10 +53,8 @@ struct HashParams {
 	uint64_t in_tab[8][2];
 	// per code c: {srol^k(fwd[c]), rev[c]}                    -> roll, outgoing base
 	uint64_t out_tab[8][2];
-	// spaced seeds (device memory, owned by the filter / call):
-	//   pos_tab[i*8+c] = {srol^(k-1-i)(fwd seed of c), srol^i(reverse seed of c)}, i<k
-	//   dc_idx = concatenated don't-care indices, seed j uses [dc_off[j], dc_off[j+1])
-	const uint64_t* pos_tab;
+	// spaced seeds: dc_idx (device memory, owned by the filter / call) = concatenated don't-care
+	// indices, seed j uses [dc_off[j], dc_off[j+1]); they are XORed back out through pos_tab
 	const uint16_t* dc_idx;
 	uint32_t dc_off[kMaxSeeds + 1];
 };
@@ -138,6 +138,7 @@ struct PartArgs {
 int part_tile_windows();
 bool part_supported_h(uint32_t h);
 uint32_t part_hash_lds_bytes(const HashParams& hp, uint32_t p0);
+bool part_hash_fits(const HashParams& hp, uint32_t p0);
 hipError_t launch_part_hash(const SeqArgs& a, const PartArgs& pa, hipStream_t s);
 hipError_t launch_part_split(void* filter, const PartArgs& pa, hipStream_t s);
 hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs& pa, hipStream_t s);

@@ -24,20 +24,25 @@
 
 namespace btlbf {
 
-static constexpr int kPartThreads = 512;
-static constexpr int kPartTile = kPartThreads * kW; // windows per round of pass A
+// 1024-thread workgroups (4 waves per SIMD; one workgroup per CU because the staging rings fill the
+// LDS) with 4 windows per lane in pass A and 16 entries per lane in pass B: <= 128 VGPRs
+static constexpr int kPartThreads = 1024;
+static constexpr int kPartW = 4;                        // windows per lane in pass A
+static constexpr int kPartTile = kPartThreads * kPartW; // windows per round of pass A
+static constexpr int kApplyThreads = 512;
 static constexpr uint32_t kChunk = 32;              // entries per chunk
 static constexpr uint32_t kSentinel = 0xffffffffu;
 static constexpr uint32_t kStageEntries = 32768;    // LDS staging: 128 KiB of uint32 entries
+static constexpr uint32_t kPartLdsBudget = 160 * 1024 - 1024; // dynamic LDS a workgroup may ask for
 
 // LDS image of the staged partitioner (carved from dynamic LDS by the kernels)
 struct PartLds {
 	uint32_t* stage;   // [P][SC] ring per bin, SC = kStageEntries / pow2ceil(P)
-	uint32_t* head;    // [P] ring read position (multiple of 32, grows forever)
-	uint32_t* tail;    // [P] ring write position
-	uint32_t* hist;    // [P] per-round counts, then tail+count totals
+	uint32_t* pt;      // [P] low 16 bits: ring write position (mod 2^16); high 16: entries in the ring
+	uint32_t* hist;    // [P] entries offered to the bin this round
+	uint32_t* fl;      // [P] entries flushed from the bin this round (multiple of 32)
 	uint32_t* written; // [P] chunks written to this workgroup's region of the bin
-	uint32_t* fout;    // [1024] output chunk index of each flush item
+	uint32_t* fout;    // [1024] output chunk index (inside `out`) of each flush item
 	uint16_t* flist;   // [1024] flush items: bin | ring chunk << 10
 	uint32_t* fcount;
 	uint32_t sc_shift; // log2(SC)
@@ -60,10 +65,10 @@ __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
 {
 	PartLds l;
 	l.stage = reinterpret_cast<uint32_t*>(base);
-	l.head = l.stage + kStageEntries;
-	l.tail = l.head + P;
-	l.hist = l.tail + P;
-	l.written = l.hist + P;
+	l.pt = l.stage + kStageEntries;
+	l.hist = l.pt + P;
+	l.fl = l.hist + P;
+	l.written = l.fl + P;
 	l.fout = l.written + P;
 	l.flist = reinterpret_cast<uint16_t*>(l.fout + 1024);
 	l.fcount = reinterpret_cast<uint32_t*>(l.flist + 1024);
@@ -78,9 +83,9 @@ template <int NT>
 __device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
 {
 	for (uint32_t b = threadIdx.x; b < P; b += NT) {
-		l.head[b] = 0;
-		l.tail[b] = 0;
+		l.pt[b] = 0;
 		l.hist[b] = 0;
+		l.fl[b] = 0;
 		l.written[b] = 0;
 	}
 	if (threadIdx.x == 0)
@@ -89,87 +94,131 @@ __device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
 
 // One round: every thread contributes E entries (bin[e] == kSentinel marks an empty slot).
 // Precondition: hist[] all zero, fcount zero, and a barrier since they were written.
-// Region r of bin b starts at out + ((uint64_t)b * n_regions + r) * cap_chunks * 32.
-// `ovf(bin, val)` must apply the entry to the filter directly.
+// Region r of bin b is chunks [(b*n_regions + r)*cap_chunks, +cap_chunks) of `out` (32-bit chunk
+// indices: the scratch holds fewer than 2^32 chunks).  `ovf(bin, val)` must apply the entry to the
+// filter directly.
+#ifdef BTLBF_PHASE_STAMPS
+#define STAMP(i)                                             \
+	do {                                                     \
+		if (threadIdx.x == 0) {                              \
+			const uint64_t t__ = __builtin_readcyclecounter(); \
+			g_stamp[i] += t__ - g_last;                      \
+			g_last = t__;                                    \
+		}                                                    \
+	} while (0)
+static __device__ uint64_t g_stamp_out[16];
+#define STAMP_DECL uint64_t g_stamp[16] = {0}, g_last = __builtin_readcyclecounter()
+#define STAMP_FLUSH                                                      \
+	do {                                                                 \
+		if (threadIdx.x == 0)                                            \
+			for (int i__ = 0; i__ < 16; ++i__)                           \
+				atomicAdd((unsigned long long*)&g_stamp_out[i__], (unsigned long long)g_stamp[i__]); \
+	} while (0)
+#define STAMP_ARGS , uint64_t (&g_stamp)[16], uint64_t& g_last
+#define STAMP_PASS , g_stamp, g_last
+#else
+#define STAMP(i)
+#define STAMP_DECL
+#define STAMP_FLUSH
+#define STAMP_ARGS
+#define STAMP_PASS
+#endif
+
 template <int NT, int E, class OVF>
 __device__ __forceinline__ void part_round(const PartLds& l, uint32_t P, const uint32_t (&bin)[E],
                                            const uint32_t (&val)[E], uint32_t* out, uint32_t n_regions,
-                                           uint32_t region, uint32_t cap_chunks, OVF&& ovf)
+                                           uint32_t region, uint32_t cap_chunks, OVF&& ovf STAMP_ARGS)
 {
 	const uint32_t tid = threadIdx.x;
 	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
-	uint32_t pos[E];
-	uint64_t staged = 0; // bit e: entry e found room in the ring before this round's flush
-	static_assert(E <= 64, "one flag bit per entry");
-	// rank inside the bin for this round
+	uint32_t rank[E];
+	uint32_t staged = 0; // bit e: entry e found room in the ring before this round's flush
+	static_assert(E <= 32, "one flag bit per entry");
 #pragma unroll
 	for (int e = 0; e < E; ++e)
-		pos[e] = bin[e] != kSentinel ? atomicAdd(&l.hist[bin[e]], 1u) : 0;
+		rank[e] = bin[e] != kSentinel ? atomicAdd(&l.hist[bin[e]], 1u) : 0;
 	__syncthreads();
-	// absolute position in the bin's stream; positions inside the ring window are staged now
+	STAMP(3);
+	// entries that fit behind what the ring already holds are staged now
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
 		if (bin[e] != kSentinel) {
-			pos[e] += l.tail[bin[e]];
-			if (pos[e] - l.head[bin[e]] < SC) {
-				l.stage[(bin[e] << l.sc_shift) + (pos[e] & ring)] = val[e];
-				staged |= 1ull << e;
+			const uint32_t w = l.pt[bin[e]];
+			if ((w >> 16) + rank[e] < SC) {
+				l.stage[(bin[e] << l.sc_shift) + ((w + rank[e]) & ring)] = val[e];
+				staged |= 1u << e;
 			}
 		}
 	}
 	__syncthreads();
-	// per bin: how many full chunks can leave; reserve their output slots in this workgroup's region
+	STAMP(4);
+	// per bin: full chunks leave; their slots in this workgroup's region come from an LDS counter
 	for (uint32_t b = tid; b < P; b += NT) {
-		const uint32_t hd = l.head[b];
-		const uint32_t tot = l.tail[b] + l.hist[b];
-		const uint32_t lm = hd + SC;
-		const uint32_t avail = (int32_t)(tot - lm) < 0 ? tot : lm;
-		const uint32_t nfl = (avail - hd) >> 5;
-		l.hist[b] = tot;
+		const uint32_t w = l.pt[b], occ = w >> 16;
+		const uint32_t tot = occ + l.hist[b];
+		const uint32_t avail = tot < SC ? tot : SC;
+		const uint32_t nfl = avail >> 5;
+		l.fl[b] = nfl << 5;
 		if (nfl) {
 			const uint32_t base = atomicAdd(l.fcount, nfl);
 			const uint32_t w0 = l.written[b];
+			const uint32_t hc = ((w - occ) & ring) >> 5; // ring chunk at the read position
+			const uint32_t o0 = (b * n_regions + region) * cap_chunks;
 			for (uint32_t c = 0; c < nfl; ++c) {
-				l.flist[base + c] = (uint16_t)(b | ((((hd >> 5) + c) & (ring >> 5)) << 10));
-				l.fout[base + c] = w0 + c;
+				l.flist[base + c] = (uint16_t)(b | (((hc + c) & (ring >> 5)) << 10));
+				l.fout[base + c] = w0 + c < cap_chunks ? o0 + w0 + c : 0xffffffffu;
 			}
 			l.written[b] = w0 + nfl;
-			l.head[b] = hd + (nfl << 5);
 		}
 	}
 	__syncthreads();
-	// flush full chunks: one half-wave (32 lanes) per chunk, one aligned 128-byte store
+	STAMP(5);
+	// flush full chunks: 8 lanes per chunk, 16 bytes per lane -> one aligned 128-byte line
 	{
 		const uint32_t n = *l.fcount;
-		const uint32_t lane32 = tid & 31;
-		for (uint32_t j = tid >> 5; j < n; j += NT / 32) {
-			const uint32_t it = l.flist[j];
-			const uint32_t b = it & 1023, rc = it >> 10, oc = l.fout[j];
-			const uint32_t v = l.stage[(b << l.sc_shift) + (rc << 5) + lane32];
-			if (oc < cap_chunks)
-				out[(((uint64_t)b * n_regions + region) * cap_chunks + oc) * kChunk + lane32] = v;
-			else
-				ovf(b, v);
+		const uint32_t l8 = tid & 7;
+		for (uint32_t j = tid >> 3; j < n; j += NT / 8) {
+			const uint32_t it = l.flist[j], oc = l.fout[j];
+			const uint32_t b = it & 1023, rc = it >> 10;
+			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(b << l.sc_shift) + (rc << 5) + l8 * 4]);
+			if (oc != 0xffffffffu) {
+				*reinterpret_cast<uint4*>(&out[(uint64_t)oc * kChunk + l8 * 4]) = v;
+			} else {
+				ovf(b, v.x);
+				ovf(b, v.y);
+				ovf(b, v.z);
+				ovf(b, v.w);
+			}
 		}
 	}
 	__syncthreads();
+	STAMP(6);
 	// entries that did not fit before the flush: into the freed ring space, else applied directly
+	{
 #pragma unroll
-	for (int e = 0; e < E; ++e) {
-		if (bin[e] != kSentinel && !((staged >> e) & 1)) {
-			if (pos[e] - l.head[bin[e]] < SC)
-				l.stage[(bin[e] << l.sc_shift) + (pos[e] & ring)] = val[e];
-			else
-				ovf(bin[e], val[e]);
+		for (int e = 0; e < E; ++e) {
+			if (bin[e] != kSentinel && !((staged >> e) & 1)) {
+				const uint32_t w = l.pt[bin[e]];
+				if ((w >> 16) + rank[e] - l.fl[bin[e]] < SC)
+					l.stage[(bin[e] << l.sc_shift) + ((w + rank[e]) & ring)] = val[e];
+				else
+					ovf(bin[e], val[e]);
+			}
 		}
 	}
+	__syncthreads();
+	STAMP(7);
 	for (uint32_t b = tid; b < P; b += NT) {
-		const uint32_t tot = l.hist[b], lm = l.head[b] + SC;
-		l.tail[b] = (int32_t)(tot - lm) < 0 ? tot : lm; // entries beyond went to the filter directly
+		const uint32_t w = l.pt[b], occ = w >> 16, f = l.fl[b];
+		const uint32_t tot = occ + l.hist[b] - f; // wants to be in the ring after the flush
+		const uint32_t nocc = tot < SC ? tot : SC; // entries beyond went to the filter directly
+		const uint32_t accepted = nocc + f - occ;
+		l.pt[b] = ((w + accepted) & 0xffffu) | (nocc << 16);
 		l.hist[b] = 0;
 	}
 	if (tid == 0)
 		*l.fcount = 0;
+	STAMP(8);
 	// the caller's next barrier orders these writes before the next round
 }
 
@@ -182,18 +231,19 @@ __device__ __forceinline__ void part_finish(const PartLds& l, uint32_t P, uint32
 	const uint32_t tid = threadIdx.x, lane32 = tid & 31;
 	const uint32_t ring = (1u << l.sc_shift) - 1;
 	for (uint32_t b = tid >> 5; b < P; b += NT / 32) {
-		const uint32_t hd = l.head[b], n = l.tail[b] - hd;
+		const uint32_t w = l.pt[b], n = w >> 16, hd = (w - n) & ring;
 		uint32_t oc = l.written[b];
+		const uint32_t o0 = (b * n_regions + region) * cap_chunks;
 		for (uint32_t c = 0; c * kChunk < n; ++c, ++oc) {
 			const uint32_t i = c * kChunk + lane32;
 			const uint32_t v = i < n ? l.stage[(b << l.sc_shift) + ((hd + i) & ring)] : kSentinel;
 			if (oc < cap_chunks)
-				out[(((uint64_t)b * n_regions + region) * cap_chunks + oc) * kChunk + lane32] = v;
+				out[(uint64_t)(o0 + oc) * kChunk + lane32] = v;
 			else if (v != kSentinel)
 				ovf(b, v);
 		}
 		if (lane32 == 0)
-			counts[(uint64_t)b * n_regions + region] = oc < cap_chunks ? oc : cap_chunks;
+			counts[b * n_regions + region] = oc < cap_chunks ? oc : cap_chunks;
 	}
 }
 
@@ -218,6 +268,7 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 	const uint32_t bin_shift = pa.bin_shift;
 	const uint32_t ent_mask = (uint32_t)((1ull << bin_shift) - 1);
 	auto ovf = [&](uint32_t b, uint32_t v) { bf_set(words, ((uint64_t)b << bin_shift) | v); };
+	const bool sharded = a.mod.shard_len != a.mod.size;
 
 	const uint64_t t_begin = a.first_tile + (uint64_t)blockIdx.x * a.tiles_per_block;
 	uint64_t t_end = t_begin + a.tiles_per_block;
@@ -229,24 +280,34 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 		tile_off = (uint32_t)((t_begin * (uint64_t)kPartTile) % L);
 	const uint32_t tile_step = L ? (uint32_t)(kPartTile % L) : 0;
 
+	STAMP_DECL;
 	for (uint64_t t = t_begin; t < t_end; ++t) {
 		const uint64_t g0 = t * (uint64_t)kPartTile;
-		const uint32_t mis = seq_stage_tile<kPartThreads>(tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+		STAMP(0);
+		const uint32_t mis = seq_stage_tile<kPartThreads, kPartW>(tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
+		STAMP(1);
 
-		uint32_t bin[kW * H], val[kW * H];
-		seq_lane_windows<SPACED>(tile, sh, a.hp, spaced_lds, tid * kW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
+		uint32_t bin[kPartW * H], val[kPartW * H];
+		seq_lane_windows<SPACED, kPartW>(tile, sh, a.hp, spaced_lds, tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
 #pragma unroll
 			for (int i = 0; i < H; ++i) {
-				const uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod) - a.mod.shard_lo;
-				const bool mine = ok && p < a.mod.shard_len;
+				uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
+				bool mine = ok;
+				if (sharded) { // wave-uniform
+					p -= a.mod.shard_lo;
+					mine = ok && p < a.mod.shard_len;
+				}
 				bin[w * H + i] = mine ? (uint32_t)(p >> bin_shift) : kSentinel;
 				val[w * H + i] = (uint32_t)p & ent_mask;
 			}
 		});
-		part_round<kPartThreads, kW * H>(pl, pa.p0, bin, val, pa.out0, pa.regions0, blockIdx.x, pa.cap0, ovf);
+		STAMP(2);
+		part_round<kPartThreads, kPartW * H>(pl, pa.p0, bin, val, pa.out0, pa.regions0, blockIdx.x, pa.cap0, ovf STAMP_PASS);
 	}
 	part_finish<kPartThreads>(pl, pa.p0, pa.out0, pa.cur0, pa.regions0, blockIdx.x, pa.cap0, ovf);
+	STAMP(9);
+	STAMP_FLUSH;
 }
 
 // ---- pass B --------------------------------------------------------------------------------------
@@ -269,6 +330,7 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 	uint32_t* cur = pa.cur1 + (uint64_t)b0 * pa.p1 * pa.regions1;
 	uint32_t* out = pa.out1 + (uint64_t)b0 * pa.p1 * pa.regions1 * pa.cap1 * kChunk;
 	constexpr int kVec = 4; // uint4 loads per thread per round -> 16 entries
+	STAMP_DECL;
 	__syncthreads();
 	for (uint32_t r = g; r < pa.regions0; r += pa.regions1) {
 		const uint64_t reg = (uint64_t)b0 * pa.regions0 + r;
@@ -297,7 +359,7 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 				const uint32_t i = base + kPartThreads * kVec + (uint32_t)v * kPartThreads + tid;
 				nxt[v] = i < n_vec ? src[i] : make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
 			}
-			part_round<kPartThreads, kVec * 4>(pl, pa.p1, bin, val, out, pa.regions1, g, pa.cap1, ovf);
+			part_round<kPartThreads, kVec * 4>(pl, pa.p1, bin, val, out, pa.regions1, g, pa.cap1, ovf STAMP_PASS);
 			__syncthreads();
 		}
 	}
@@ -306,7 +368,7 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 
 // ---- pass C --------------------------------------------------------------------------------------
 // one workgroup per segment; the segment's entries sit in `n_regions` regions of `cap` chunks each
-__global__ __launch_bounds__(kPartThreads) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
+__global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
                                                                  uint32_t seg_shift, const uint32_t* cur,
                                                                  const uint32_t* ent, uint32_t cap,
                                                                  uint32_t n_regions)
@@ -319,7 +381,7 @@ __global__ __launch_bounds__(kPartThreads) void part_apply_kernel(uint8_t* filte
 		any = 0;
 	__syncthreads();
 	uint32_t mine = 0;
-	for (uint32_t r = tid; r < n_regions; r += kPartThreads)
+	for (uint32_t r = tid; r < n_regions; r += kApplyThreads)
 		mine |= cur[seg * n_regions + r];
 	if (mine)
 		any = 1;
@@ -334,7 +396,7 @@ __global__ __launch_bounds__(kPartThreads) void part_apply_kernel(uint8_t* filte
 	const uint32_t n_vec = (uint32_t)((nbytes + 15) / 16); // the allocation is padded to 16 bytes
 	uint4* lds4 = reinterpret_cast<uint4*>(dyn);
 	uint4* g4 = reinterpret_cast<uint4*>(filter + byte0);
-	for (uint32_t i = tid; i < n_vec; i += kPartThreads)
+	for (uint32_t i = tid; i < n_vec; i += kApplyThreads)
 		lds4[i] = g4[i];
 	__syncthreads();
 	uint32_t* lds = reinterpret_cast<uint32_t*>(dyn);
@@ -345,7 +407,7 @@ __global__ __launch_bounds__(kPartThreads) void part_apply_kernel(uint8_t* filte
 			n_chunks = cap;
 		const uint4* e4 = reinterpret_cast<const uint4*>(ent + reg * cap * kChunk);
 		const uint32_t n_ev = n_chunks * (kChunk / 4);
-		for (uint32_t i = tid; i < n_ev; i += kPartThreads) {
+		for (uint32_t i = tid; i < n_ev; i += kApplyThreads) {
 			const uint4 q = e4[i];
 			const uint32_t e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -355,16 +417,36 @@ __global__ __launch_bounds__(kPartThreads) void part_apply_kernel(uint8_t* filte
 		}
 	}
 	__syncthreads();
-	for (uint32_t i = tid; i < n_vec; i += kPartThreads)
+	for (uint32_t i = tid; i < n_vec; i += kApplyThreads)
 		g4[i] = lds4[i];
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
+#ifdef BTLBF_PHASE_STAMPS
+extern "C" void btlbf_debug_stamps(uint64_t* out16)
+{
+	(void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp_out), sizeof(uint64_t) * 16);
+	uint64_t z[16] = {0};
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_out), z, sizeof z);
+}
+#endif
 int part_tile_windows() { return kPartTile; }
 
 uint32_t part_hash_lds_bytes(const HashParams& hp, uint32_t p0)
 {
 	return seq_tile_cap(kPartTile, hp.k) + seq_spaced_bytes(hp) + part_lds_bytes(p0);
+}
+
+// can pass A run for this hash configuration at all (possibly without the positional table)?
+bool part_hash_fits(const HashParams& hp_in, uint32_t p0)
+{
+	HashParams hp = hp_in;
+	if (part_hash_lds_bytes(hp, p0) <= kPartLdsBudget)
+		return true;
+	if (hp.n_seeds)
+		return false;
+	hp.use_pos_tab = 0;
+	return part_hash_lds_bytes(hp, p0) <= kPartLdsBudget;
 }
 
 template <int H>
@@ -391,7 +473,7 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartArgs& pa, unsigned b
 	return hipGetLastError();
 }
 
-bool part_supported_h(uint32_t h) { return h >= 1 && h <= 5; }
+bool part_supported_h(uint32_t h) { return h >= 1 && h <= 8; }
 
 // pass A over tiles [a.first_tile, +a.n_tiles) (units: kPartTile windows); exactly pa.regions0
 // workgroups are launched (one region each; idle ones still publish empty counts)
@@ -400,6 +482,10 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartArgs& pa, hipStream_t
 	SeqArgs a = a_in;
 	if (a.n_tiles == 0)
 		return hipSuccess;
+	// LDS is nearly full with the staging rings: drop the positional table (Horner start-up
+	// instead) when it does not fit; spaced seeds cannot do without it
+	if (a.hp.n_seeds == 0 && part_hash_lds_bytes(a.hp, pa.p0) > kPartLdsBudget)
+		a.hp.use_pos_tab = 0;
 	const unsigned blocks = pa.regions0;
 	a.tiles_per_block = (a.n_tiles + blocks - 1) / blocks;
 	const size_t dyn = part_hash_lds_bytes(a.hp, pa.p0);
@@ -409,6 +495,9 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartArgs& pa, hipStream_t
 	case 3: return launch_hash_h<3>(a, pa, blocks, dyn, s);
 	case 4: return launch_hash_h<4>(a, pa, blocks, dyn, s);
 	case 5: return launch_hash_h<5>(a, pa, blocks, dyn, s);
+	case 6: return launch_hash_h<6>(a, pa, blocks, dyn, s);
+	case 7: return launch_hash_h<7>(a, pa, blocks, dyn, s);
+	case 8: return launch_hash_h<8>(a, pa, blocks, dyn, s);
 	default: return hipErrorInvalidValue;
 	}
 }
@@ -432,7 +521,7 @@ hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs&
 	if (e != hipSuccess)
 		return e;
 	const bool two = pa.levels == 2;
-	hipLaunchKernelGGL(part_apply_kernel, dim3((unsigned)pa.n_seg), dim3(kPartThreads), dyn, s,
+	hipLaunchKernelGGL(part_apply_kernel, dim3((unsigned)pa.n_seg), dim3(kApplyThreads), dyn, s,
 	                   static_cast<uint8_t*>(filter), local_bytes, pa.seg_shift, two ? pa.cur1 : pa.cur0,
 	                   two ? pa.out1 : pa.out0, two ? pa.cap1 : pa.cap0, two ? pa.regions1 : pa.regions0);
 	return hipGetLastError();

@@ -15,7 +15,7 @@
 
 namespace btlbf {
 
-static constexpr int kW = 8; // consecutive windows per lane
+static constexpr int kW = 8; // consecutive windows per lane (default)
 
 struct __attribute__((aligned(16))) U64x2 {
 	uint64_t x, y;
@@ -53,12 +53,16 @@ __host__ __device__ inline uint32_t seq_tile_cap(uint32_t tile_windows, uint32_t
 {
 	return ((tile_windows + k - 1 + 15 + 15) / 16) * 16;
 }
-// bytes of dynamic LDS for the spaced-seed tables that follow the tile
+// bytes of dynamic LDS for the tables that follow the tile: the positional seed table
+// pos_tab[i*8+c] = {srol^(k-1-i)(fwd[c]), srol^i(rev[c])} (when hp.use_pos_tab) and the spaced seeds'
+// don't-care index list
+__host__ __device__ inline uint32_t seq_pos_tab_bytes(const HashParams& hp)
+{
+	return hp.use_pos_tab ? hp.k * kNumCodes * 16 : 0;
+}
 __host__ __device__ inline uint32_t seq_spaced_bytes(const HashParams& hp)
 {
-	if (hp.n_seeds == 0)
-		return 0;
-	return hp.k * kNumCodes * 16 + ((hp.dc_off[hp.n_seeds] * 2 + 15) / 16) * 16;
+	return seq_pos_tab_bytes(hp) + (hp.n_seeds ? ((hp.dc_off[hp.n_seeds] * 2 + 15) / 16) * 16 : 0);
 }
 
 // one-time table setup; callers __syncthreads() before first use (seq_stage_tile does)
@@ -77,12 +81,18 @@ __device__ __forceinline__ void seq_setup_tables(SeqShared& sh, const HashParams
 		sh.cnt_valid = 0;
 		sh.cnt_hit = 0;
 	}
-	if (SPACED) {
+	if (hp.use_pos_tab) {
+		// positional seed table, built once per workgroup from the four seeds:
+		// fwd[c] = init_tab[c][0], rev[c] = out_tab[c][1] (internal.hpp)
 		const uint32_t k = hp.k;
-		uint64_t* pt = reinterpret_cast<uint64_t*>(spaced_lds);
-		for (uint32_t i = tid; i < k * kNumCodes * 2; i += NT)
-			pt[i] = hp.pos_tab[i];
-		uint16_t* di = reinterpret_cast<uint16_t*>(spaced_lds + k * kNumCodes * 16);
+		U64x2* pt = reinterpret_cast<U64x2*>(spaced_lds);
+		for (uint32_t i = tid; i < k * kNumCodes; i += NT) {
+			const uint32_t pos = i / kNumCodes, c = i % kNumCodes;
+			pt[i] = U64x2{srol_n(hp.init_tab[c][0], k - 1 - pos), srol_n(hp.out_tab[c][1], pos)};
+		}
+	}
+	if (SPACED) {
+		uint16_t* di = reinterpret_cast<uint16_t*>(spaced_lds + seq_pos_tab_bytes(hp));
 		const uint32_t ndc = hp.dc_off[hp.n_seeds];
 		for (uint32_t i = tid; i < ndc; i += NT)
 			di[i] = hp.dc_idx[i];
@@ -92,12 +102,12 @@ __device__ __forceinline__ void seq_setup_tables(SeqShared& sh, const HashParams
 // Stage the tile that starts at byte offset g0.  Ends with a __syncthreads(); begins with one so
 // that the previous tile has been fully consumed.  tile_off = g0 % read_len (uniform layout only).
 // Returns the misalignment `mis`: LDS index of window w's first base is w + mis.
-template <int NT>
+template <int NT, int KW = kW>
 __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_cap, SeqShared& sh,
                                                    const uint8_t* seq, uint64_t len, const LayoutParams& lay,
                                                    uint32_t k, uint64_t g0, uint32_t tile_off)
 {
-	constexpr uint32_t kTileW = NT * kW;
+	constexpr uint32_t kTileW = NT * KW;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t L = lay.read_len;
 	const uint64_t* starts = lay.starts;
@@ -185,19 +195,34 @@ struct WinHash {
 	}
 };
 
-// Walk the lane's kW consecutive windows (first base at LDS index li0) and call
+// Walk the lane's KW consecutive windows (first base at LDS index li0) and call
 // f(w, clean, const WinHash<SPACED>&) for each.
-template <bool SPACED, class F>
+template <bool SPACED, int KW = kW, class F>
 __device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqShared& sh, const HashParams& hp,
                                                  const uint8_t* spaced_lds, uint32_t li0, F&& f)
 {
 	const uint32_t k = hp.k;
 	const U64x2* pos_tab = reinterpret_cast<const U64x2*>(spaced_lds);
-	const uint16_t* dc_idx = reinterpret_cast<const uint16_t*>(spaced_lds + (SPACED ? k * kNumCodes * 16 : 0));
+	const uint16_t* dc_idx = reinterpret_cast<const uint16_t*>(spaced_lds + seq_pos_tab_bytes(hp));
 	uint64_t fh, rh;
 	uint32_t cnt = 0; // valid, non-start bases among the k-1 bases after the window's first
 	uint32_t first_valid;
-	{
+	if (hp.use_pos_tab) {
+		// first window from the positional table: one 16-byte LDS read and two XORs per base
+		uint32_t e = tile[li0];
+		first_valid = (e >> 3) & 1;
+		U64x2 tt = pos_tab[e & kCodeMask];
+		fh = tt.x;
+		rh = tt.y;
+		for (uint32_t i = 1; i < k; ++i) {
+			e = tile[li0 + i];
+			tt = pos_tab[i * kNumCodes + (e & kCodeMask)];
+			fh ^= tt.x;
+			rh ^= tt.y;
+			cnt += ((e & (kBaseValid | kBaseStart)) == kBaseValid);
+		}
+	} else {
+		// Horner form (large k: the positional table would not fit in LDS)
 		uint32_t e = tile[li0];
 		first_valid = (e >> 3) & 1;
 		U64x2 tt = sh.init_tab[e & kCodeMask];
@@ -212,7 +237,7 @@ __device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqS
 		}
 	}
 #pragma unroll
-	for (int w = 0; w < kW; ++w) {
+	for (int w = 0; w < KW; ++w) {
 		if (w > 0) {
 			const uint32_t eo = tile[li0 + w - 1];
 			const uint32_t ei = tile[li0 + w - 1 + k];

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 		(void)bitbuf;
 		const bool pipelined = (OP == OP_BF_CONTAINS) && !SPACED && h <= kPipe;
 
-		seq_lane_windows<SPACED>(tile, sh, a.hp, spaced_lds, tid * kW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
+		seq_lane_windows<SPACED, kW>(tile, sh, a.hp, spaced_lds, tid * kW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
 			valid_mask |= (uint32_t)ok << w;
 			const uint64_t gp = g0 + tid * kW + w; // byte offset of this window
 
