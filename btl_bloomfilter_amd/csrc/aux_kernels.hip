@@ -156,18 +156,18 @@ hipError_t launch_serial_seq_update(const SeqArgs& a, int op, const uint64_t* ha
 }
 
 // ---- popcount ----------------------------------------------------------------------------------
-// mode 0: set bits; mode 1: non-zero bytes; mode 2: bytes >= threshold.  nbytes is padded to 16 by
-// the allocator (padding is zero), so the kernel reads whole uint4s.
-__global__ __launch_bounds__(256) void popcount_kernel(const uint4* data, uint64_t n_vec, int mode,
+// mode 0: set bits; mode 1: non-zero bytes; mode 2: bytes >= threshold.  nbytes must be a multiple
+// of 8 (bitmaps are whole uint64_t words; filter arrays are zero-padded to 16 bytes).
+__global__ __launch_bounds__(256) void popcount_kernel(const uint2* data, uint64_t n_vec, int mode,
                                                        uint32_t threshold, unsigned long long* out)
 {
 	unsigned long long acc = 0;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec;
 	     i += (uint64_t)gridDim.x * blockDim.x) {
-		const uint4 v = data[i];
-		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		const uint2 v = data[i];
+		const uint32_t w[2] = {v.x, v.y};
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
+		for (int q = 0; q < 2; ++q) {
 			if (mode == 0) {
 				acc += __popc(w[q]);
 			} else {
@@ -189,14 +189,16 @@ __global__ __launch_bounds__(256) void popcount_kernel(const uint4* data, uint64
 hipError_t launch_popcount(const void* data, uint64_t nbytes, int mode, uint32_t threshold,
                            unsigned long long* out, hipStream_t s)
 {
-	const uint64_t n_vec = (nbytes + 15) / 16;
+	if (nbytes % 8)
+		return hipErrorInvalidValue;
+	const uint64_t n_vec = nbytes / 8;
 	if (n_vec == 0)
 		return hipSuccess;
 	uint64_t blocks = (n_vec + 255) / 256;
 	if (blocks > 4096)
 		blocks = 4096;
 	hipLaunchKernelGGL(popcount_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-	                   static_cast<const uint4*>(data), n_vec, mode, threshold, out);
+	                   static_cast<const uint2*>(data), n_vec, mode, threshold, out);
 	return hipGetLastError();
 }
 

@@ -78,6 +78,7 @@ struct btlbf_filter {
 	unsigned long long* d_scalar = nullptr; // 4 x u64
 	// partitioned insert (partition_kernels.hip): mode + cached scratch
 	int insert_mode = BTLBF_INSERT_AUTO;
+	int query_mode = BTLBF_INSERT_AUTO;
 	void* d_part = nullptr;
 	uint64_t part_bytes = 0;
 	uint64_t part_budget = 0; // 0 = derive from free HBM
@@ -391,6 +392,12 @@ int make_filter(btlbf_filter** out, int kind, uint64_t size, uint64_t size_bytes
 		else if (!strcmp(m, "partitioned"))
 			f->insert_mode = BTLBF_INSERT_PARTITIONED;
 	}
+	if (const char* m = getenv("BTLBF_QUERY_MODE")) {
+		if (!strcmp(m, "direct"))
+			f->query_mode = BTLBF_INSERT_DIRECT;
+		else if (!strcmp(m, "partitioned"))
+			f->query_mode = BTLBF_INSERT_PARTITIONED;
+	}
 	hipError_t e = hipMalloc(&f->d_data, f->alloc_bytes);
 	if (e != hipSuccess) {
 		delete f;
@@ -531,6 +538,14 @@ extern "C" int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch
 		return fail(BTLBF_EINVAL, "bad insert mode");
 	f->insert_mode = mode;
 	f->part_budget = scratch_bytes;
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_set_query_mode(btlbf_filter* f, int mode)
+{
+	if (!f || mode < BTLBF_INSERT_AUTO || mode > BTLBF_INSERT_PARTITIONED)
+		return fail(BTLBF_EINVAL, "bad query mode");
+	f->query_mode = mode;
 	return BTLBF_OK;
 }
 
@@ -762,6 +777,11 @@ extern "C" int btlbf_store(btlbf_filter* f, const char* path)
 // -------------------------------------------------------------------------------------------------
 namespace {
 
+// defined further down, next to the partitioned insert
+int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, uint8_t* valid_bits,
+                         uint64_t* counts, hipStream_t s, bool* done);
+int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* yes);
+
 int seq_precheck(const btlbf_filter* f, uint64_t len)
 {
 	if (!f)
@@ -831,7 +851,30 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 	a.valid_bits = static_cast<uint8_t*>(ob_valid.d);
 	a.counts = static_cast<uint64_t*>(ob_cnt.d);
 	a.min_out = static_cast<uint8_t*>(ob_min.d);
-	HIP_TRY(launch_seq_op(op, a, s));
+	bool done = false;
+	if (op == OP_BF_CONTAINS) {
+		bool yes = false;
+		if ((rc = want_partitioned_query(f, a, s, &yes)))
+			return rc;
+		if (yes) {
+			DevBuf tmp_hit; // the partitioned path needs a hit bitmap to refine even if the caller wants counts only
+			uint8_t* hb = a.hit_bits;
+			if (!hb) {
+				HIP_TRY(tmp_hit.alloc(bitmap_bytes(len) + 16));
+				hb = tmp_hit.as<uint8_t>();
+			}
+			SeqArgs b = a;
+			b.hit_bits = nullptr;
+			b.valid_bits = nullptr;
+			b.counts = nullptr;
+			if ((rc = partitioned_contains(f, b, hb, a.valid_bits, a.counts, s, &done)))
+				return rc;
+			if (done && !a.hit_bits)
+				HIP_TRY(hipStreamSynchronize(s)); // tmp_hit is freed on return
+		}
+	}
+	if (!done)
+		HIP_TRY(launch_seq_op(op, a, s));
 	if ((rc = ob_hit.finish(s)) || (rc = ob_valid.finish(s)) || (rc = ob_cnt.finish(s)) ||
 	    (rc = ob_min.finish(s)))
 		return rc;
@@ -853,6 +896,11 @@ struct PartPlan {
 	uint64_t bytes_cur0, bytes_cur1, bytes_out0, bytes_out1, bytes_total;
 };
 
+// partitioned query: room for the failed positions of one batch and their hash set
+static constexpr uint64_t kFailCap = 4ull << 20;             // entries
+static constexpr uint64_t kFailTableSlots = 2 * kFailCap;    // power of two
+static constexpr uint64_t kFailBytes = 256 + kFailCap * 8 + kFailTableSlots * 8;
+
 // chunks a region needs for `mean_entries` expected entries (Poisson: mean + 8 sigma) plus the
 // partially filled chunks flushed at kernel end
 uint32_t chunks_for(double mean_entries, uint32_t tail_chunks)
@@ -862,7 +910,7 @@ uint32_t chunks_for(double mean_entries, uint32_t tail_chunks)
 }
 
 bool plan_partition(const btlbf_filter* f, uint64_t total_tiles, double probes_per_tile, unsigned blocks_a,
-                    uint64_t budget, PartPlan& pl)
+                    uint64_t budget, uint64_t extra_bytes, PartPlan& pl)
 {
 	const uint64_t mloc = f->mod.shard_len;
 	PartArgs& pa = pl.pa;
@@ -899,7 +947,7 @@ bool plan_partition(const btlbf_filter* f, uint64_t total_tiles, double probes_p
 		pl.bytes_cur1 = pa.levels == 2 ? ((uint64_t)pa.p0 * pa.p1 * pa.regions1 * 4 + 255) / 256 * 256 : 0;
 		pl.bytes_out0 = (uint64_t)pa.p0 * pa.regions0 * pa.cap0 * 128;
 		pl.bytes_out1 = pa.levels == 2 ? (uint64_t)pa.p0 * pa.p1 * pa.regions1 * pa.cap1 * 128 : 0;
-		pl.bytes_total = pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0 + pl.bytes_out1;
+		pl.bytes_total = pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0 + pl.bytes_out1 + extra_bytes;
 		if (pl.bytes_total <= budget || tiles <= 1)
 			break;
 		// shrink the batch in proportion (plus a little) and try again
@@ -921,15 +969,19 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len)
 	if (f->insert_mode == BTLBF_INSERT_PARTITIONED)
 		return true;
 	// auto: one sweep of the local array (read + write) must be cheaper than the random atomics it
-	// replaces: ~ 2*bytes/5e12 s against probes/21e9 s, with a 2x margin
-	return (double)len * f->hp.h >= 0.02 * (double)f->local_bytes;
+	// replaces: ~ 2*bytes/5e12 s against probes/21e9 s, with a 2x margin; and the batch must be big
+	// enough to be worth five launches
+	const double probes = (double)len * f->hp.h;
+	return probes >= 0.02 * (double)f->local_bytes && probes >= 4.0e6;
 }
 
-int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* done)
+// plan + (re)allocate the scratch; *ok = false means "not applicable, use the direct kernel"
+int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, PartPlan& pl, uint64_t* total_tiles,
+                 bool* ok)
 {
-	*done = false;
+	*ok = false;
 	const uint64_t tile_w = (uint64_t)part_tile_windows();
-	const uint64_t total_tiles = (base.len + tile_w - 1) / tile_w;
+	*total_tiles = (base.len + tile_w - 1) / tile_w;
 	int cus = 256;
 	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, f->device);
 	const unsigned blocks_a = (unsigned)cus; // one workgroup per CU (LDS-bound)
@@ -945,9 +997,8 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 		budget = (uint64_t)((double)(free_b + f->part_bytes) * 0.80);
 	}
-	PartPlan pl;
-	if (!plan_partition(f, total_tiles, probes_per_tile, blocks_a, budget, pl))
-		return BTLBF_OK; // not applicable: caller falls back to the direct kernel
+	if (!plan_partition(f, *total_tiles, probes_per_tile, blocks_a, budget, extra_bytes, pl))
+		return BTLBF_OK;
 	if (!part_hash_fits(f->hp, pl.pa.p0))
 		return BTLBF_OK;
 	if (pl.bytes_total > f->part_bytes) {
@@ -966,17 +1017,136 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 	pl.pa.cur1 = reinterpret_cast<uint32_t*>(p + pl.bytes_cur0);
 	pl.pa.out0 = reinterpret_cast<uint32_t*>(p + pl.bytes_cur0 + pl.bytes_cur1);
 	pl.pa.out1 = reinterpret_cast<uint32_t*>(p + pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0);
+	if (extra_bytes) {
+		uint8_t* x = p + pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0 + pl.bytes_out1;
+		pl.pa.fail_count = reinterpret_cast<unsigned long long*>(x);
+		pl.pa.fail_list = reinterpret_cast<uint64_t*>(x + 256);
+		pl.pa.fail_cap = kFailCap;
+	}
+	*ok = true;
+	return BTLBF_OK;
+}
+
+int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* done)
+{
+	*done = false;
+	PartPlan pl;
+	uint64_t total_tiles = 0;
+	bool ok = false;
+	int rc = part_prepare(f, base, 0, pl, &total_tiles, &ok);
+	if (rc || !ok)
+		return rc;
 	for (uint64_t t0 = 0; t0 < total_tiles; t0 += pl.tiles_per_batch) {
 		SeqArgs a = base;
 		a.first_tile = t0;
 		a.n_tiles = std::min<uint64_t>(pl.tiles_per_batch, total_tiles - t0);
 		HIP_TRY(launch_part_hash(a, pl.pa, s)); // every writer publishes all of its region counts
-
 		if (pl.pa.levels == 2)
 			HIP_TRY(launch_part_split(f->d_data, pl.pa, s));
-		HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, s));
+		HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, 0, s));
 	}
 	*done = true;
+	return BTLBF_OK;
+}
+
+// Partitioned contains(): positions are partitioned exactly as for insert and
+// TESTED against each segment in LDS; positions found clear go to a (small) fail list.  A batch
+// without failures is finished: every clean window hits.  Otherwise the failed positions become a
+// cache-resident hash set and one more hashing pass clears the windows that own one of them.  Too
+// many failures (a miss-heavy batch) and the batch is redone by the direct gather kernel.
+// hit_bits (device) is required; valid_bits and counts are optional.
+int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, uint8_t* valid_bits,
+                         uint64_t* counts, hipStream_t s, bool* done)
+{
+	*done = false;
+	PartPlan pl;
+	uint64_t total_tiles = 0;
+	bool ok = false;
+	int rc = part_prepare(f, base, kFailBytes, pl, &total_tiles, &ok);
+	if (rc || !ok)
+		return rc;
+	uint64_t* table = pl.pa.fail_list + kFailCap;
+	if (counts)
+		HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
+	const uint64_t seq_tiles_all = (base.len + seq_tile_windows() - 1) / seq_tile_windows();
+	const uint64_t ratio = (uint64_t)part_tile_windows() / seq_tile_windows();
+	for (uint64_t t0 = 0; t0 < total_tiles; t0 += pl.tiles_per_batch) {
+		SeqArgs a = base;
+		a.first_tile = t0;
+		a.n_tiles = std::min<uint64_t>(pl.tiles_per_batch, total_tiles - t0);
+		a.hit_bits = hit_bits;
+		a.valid_bits = valid_bits;
+		a.counts = counts; // pass A adds the clean-window count to counts[0]
+		HIP_TRY(hipMemsetAsync(pl.pa.fail_count, 0, 8, s));
+		HIP_TRY(launch_part_hash(a, pl.pa, s));
+		if (pl.pa.levels == 2)
+			HIP_TRY(launch_part_split(f->d_data, pl.pa, s));
+		HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, 1, s));
+		unsigned long long n_fail = 0;
+		HIP_TRY(hipMemcpyAsync(&n_fail, pl.pa.fail_count, 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		if (n_fail == 0)
+			continue;
+		// redo / refine this batch's window range with the direct kernels (their tiles are smaller)
+		SeqArgs d = base;
+		d.first_tile = t0 * ratio;
+		d.n_tiles = std::min<uint64_t>(a.n_tiles * ratio, seq_tiles_all - d.first_tile);
+		d.hit_bits = hit_bits;
+		d.valid_bits = nullptr;
+		d.counts = nullptr;
+		if (n_fail > kFailCap) {
+			HIP_TRY(launch_seq_op(OP_BF_CONTAINS, d, s));
+		} else {
+			HIP_TRY(hipMemsetAsync(table, 0, kFailTableSlots * 8, s));
+			HIP_TRY(launch_failset_build(pl.pa.fail_list, n_fail, table, kFailTableSlots - 1, s));
+			d.buckets = table;
+			d.bucket_cap = kFailTableSlots - 1;
+			HIP_TRY(launch_seq_op(OP_BF_RESOLVE, d, s));
+		}
+	}
+	if (counts) // hits = set bits of the final bitmap
+		HIP_TRY(launch_popcount(hit_bits, ((base.len + 63) / 64) * 8, 0, 0,
+		                        reinterpret_cast<unsigned long long*>(counts) + 1, s));
+	*done = true;
+	return BTLBF_OK;
+}
+
+// AUTO decision for contains(): large batch, and a sample of tiles says nearly every k-mer hits
+int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* yes)
+{
+	*yes = false;
+	if (f->kind != BTLBF_BLOOM || f->shard_count != 1 || f->query_mode == BTLBF_INSERT_DIRECT)
+		return BTLBF_OK;
+	if (!part_supported_h(f->hp.h) || base.len == 0)
+		return BTLBF_OK;
+	if (f->query_mode == BTLBF_INSERT_PARTITIONED) {
+		*yes = true;
+		return BTLBF_OK;
+	}
+	if ((double)base.len * f->hp.h < 0.02 * (double)f->local_bytes || (double)base.len * f->hp.h < 4.0e6)
+		return BTLBF_OK;
+	// sample 64 tiles spread over the buffer with the direct kernel
+	const uint64_t tiles = (base.len + seq_tile_windows() - 1) / seq_tile_windows();
+	const unsigned n_s = (unsigned)std::min<uint64_t>(64, tiles);
+	HIP_TRY(hipMemsetAsync(f->d_scalar, 0, 16, s));
+	for (unsigned i = 0; i < n_s; ++i) {
+		SeqArgs a = base;
+		a.first_tile = (tiles / n_s) * i;
+		a.n_tiles = 1;
+		a.hit_bits = nullptr;
+		a.valid_bits = nullptr;
+		a.counts = reinterpret_cast<uint64_t*>(f->d_scalar);
+		HIP_TRY(launch_seq_op(OP_BF_CONTAINS, a, s));
+	}
+	unsigned long long c[2] = {0, 0};
+	HIP_TRY(hipMemcpyAsync(c, f->d_scalar, 16, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if (c[0] == 0)
+		return BTLBF_OK;
+	// expected failed probes in the whole call (at most h per missing k-mer) must stay well below
+	// what the fail list holds per batch
+	const double miss = (double)(c[0] - c[1]) / (double)c[0];
+	*yes = miss * (double)base.len * f->hp.h < 0.25 * (double)kFailCap;
 	return BTLBF_OK;
 }
 
@@ -1312,8 +1482,8 @@ extern "C" int btlbf_popcount_bits(const void* dev_buf, uint64_t nbytes, uint64_
 {
 	if (!out || (nbytes && !dev_buf))
 		return fail(BTLBF_EINVAL, "null argument");
-	if (nbytes % 16)
-		return fail(BTLBF_EINVAL, "nbytes must be a multiple of 16");
+	if (nbytes % 8)
+		return fail(BTLBF_EINVAL, "nbytes must be a multiple of 8");
 	DeviceGuard g(device);
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	DevBuf acc;

@@ -74,7 +74,8 @@ enum SeqOp : int {
 	OP_CBF_INC_ALL = 4,
 	OP_CBF_QUERY = 5,    // contains + optional min counts
 	OP_HASH_ONLY = 6,    // dense hashes / valid / strand output
-	OP_POSITIONS = 7     // bucket positions by owning shard (multi-GPU)
+	OP_POSITIONS = 7,    // bucket positions by owning shard (multi-GPU)
+	OP_BF_RESOLVE = 8    // partitioned query, second step: windows with a probe in the failed-position set miss
 };
 
 // operations on precomputed hash rows (aux_kernels.hip)
@@ -132,6 +133,10 @@ struct PartArgs {
 	uint32_t* cur1;              // [p0*p1*regions1]
 	uint32_t* out0;              // [p0*regions0][cap0][32]
 	uint32_t* out1;              // [p0*p1*regions1][cap1][32]
+	// partitioned query: positions whose bit was found clear are appended here
+	uint64_t* fail_list;
+	unsigned long long* fail_count;
+	uint64_t fail_cap;
 };
 
 // launchers (defined in the .hip files)
@@ -141,7 +146,8 @@ uint32_t part_hash_lds_bytes(const HashParams& hp, uint32_t p0);
 bool part_hash_fits(const HashParams& hp, uint32_t p0);
 hipError_t launch_part_hash(const SeqArgs& a, const PartArgs& pa, hipStream_t s);
 hipError_t launch_part_split(void* filter, const PartArgs& pa, hipStream_t s);
-hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs& pa, hipStream_t s);
+hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs& pa, int test_only, hipStream_t s);
+hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t* table, uint64_t mask, hipStream_t s);
 hipError_t launch_seq_op(int op, const SeqArgs& a, hipStream_t s);
 hipError_t launch_hash_op(int op, void* filter, const ModParams& mod, uint32_t h, uint32_t threshold,
                           const uint64_t* hashes, uint64_t n, uint8_t* out, int serial, hipStream_t s);

@@ -250,7 +250,16 @@ __device__ __forceinline__ void part_finish(const PartLds& l, uint32_t P, uint32
 // ---- pass A --------------------------------------------------------------------------------------
 // bin = local_position >> bin_shift ; entry = local_position & ((1 << bin_shift) - 1)
 // region = blockIdx.x (gridDim.x == pa.regions0)
-template <int H, bool POW2, bool SPACED>
+// QUERY = true: positions are partitioned for testing, not setting; an entry that cannot be staged
+// is tested against the filter right away and reported through the fail list if its bit is clear
+__device__ __forceinline__ void part_report_fail(const PartArgs& pa, uint64_t local_pos)
+{
+	const unsigned long long i = atomicAdd(pa.fail_count, 1ull);
+	if (i < pa.fail_cap)
+		pa.fail_list[i] = local_pos;
+}
+
+template <int H, bool POW2, bool SPACED, bool QUERY>
 __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a, const PartArgs pa)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
@@ -267,8 +276,16 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 	uint32_t* words = static_cast<uint32_t*>(a.filter);
 	const uint32_t bin_shift = pa.bin_shift;
 	const uint32_t ent_mask = (uint32_t)((1ull << bin_shift) - 1);
-	auto ovf = [&](uint32_t b, uint32_t v) { bf_set(words, ((uint64_t)b << bin_shift) | v); };
+	auto ovf = [&](uint32_t b, uint32_t v) {
+		const uint64_t lp = ((uint64_t)b << bin_shift) | v;
+		if (!QUERY)
+			bf_set(words, lp);
+		else if (!((bf_word(words, lp) >> (lp & 31)) & 1u))
+			part_report_fail(pa, lp);
+	};
 	const bool sharded = a.mod.shard_len != a.mod.size;
+	const uint64_t out_bytes = ((a.len + 63) / 64) * 8;
+	uint32_t my_valid = 0;
 
 	const uint64_t t_begin = a.first_tile + (uint64_t)blockIdx.x * a.tiles_per_block;
 	uint64_t t_end = t_begin + a.tiles_per_block;
@@ -289,7 +306,9 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 		STAMP(1);
 
 		uint32_t bin[kPartW * H], val[kPartW * H];
+		uint32_t vmask = 0;
 		seq_lane_windows<SPACED, kPartW>(tile, sh, a.hp, spaced_lds, tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
+			vmask |= (uint32_t)ok << w;
 #pragma unroll
 			for (int i = 0; i < H; ++i) {
 				uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
@@ -302,10 +321,29 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 				val[w * H + i] = (uint32_t)p & ent_mask;
 			}
 		});
+		if (a.valid_bits || a.hit_bits) {
+			// two lanes (4 windows each) make one byte of the per-window bitmaps
+			static_assert(kPartW == 4, "nibble packing");
+			const uint32_t other = __shfl_xor(vmask, 1, 64);
+			const uint64_t ob = (g0 >> 3) + (tid >> 1);
+			if (!(tid & 1) && ob < out_bytes) {
+				const uint8_t v = (uint8_t)(vmask | (other << 4));
+				if (a.valid_bits)
+					a.valid_bits[ob] = v;
+				if (a.hit_bits)
+					a.hit_bits[ob] = v; // a query starts from "every clean window hits"
+			}
+		}
+		my_valid += __popc(vmask);
 		STAMP(2);
 		part_round<kPartThreads, kPartW * H>(pl, pa.p0, bin, val, pa.out0, pa.regions0, blockIdx.x, pa.cap0, ovf STAMP_PASS);
 	}
 	part_finish<kPartThreads>(pl, pa.p0, pa.out0, pa.cur0, pa.regions0, blockIdx.x, pa.cap0, ovf);
+	if (a.counts) {
+		const uint32_t wv = wave_sum(my_valid);
+		if ((tid & 63) == 0 && wv)
+			atomicAdd(reinterpret_cast<unsigned long long*>(a.counts), (unsigned long long)wv);
+	}
 	STAMP(9);
 	STAMP_FLUSH;
 }
@@ -314,6 +352,7 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 // workgroup (b0, g): blockIdx.x = b0 * regions1 + g.  It consumes pass-A regions g, g+regions1, ...
 // of level-0 bin b0 and writes region g of every sub-bin of b0.
 // entry e -> sub-bin e >> seg_shift, new entry e & seg_mask.
+template <bool QUERY>
 __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, const PartArgs pa)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
@@ -325,7 +364,13 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 	const uint32_t seg_shift = pa.seg_shift;
 	const uint32_t seg_mask = (1u << seg_shift) - 1;
 	const uint64_t bin_base = (uint64_t)b0 << pa.bin_shift;
-	auto ovf = [&](uint32_t sub, uint32_t v) { bf_set(words, bin_base | ((uint64_t)sub << seg_shift) | v); };
+	auto ovf = [&](uint32_t sub, uint32_t v) {
+		const uint64_t lp = bin_base | ((uint64_t)sub << seg_shift) | v;
+		if (!QUERY)
+			bf_set(words, lp);
+		else if (!((bf_word(words, lp) >> (lp & 31)) & 1u))
+			part_report_fail(pa, lp);
+	};
 
 	uint32_t* cur = pa.cur1 + (uint64_t)b0 * pa.p1 * pa.regions1;
 	uint32_t* out = pa.out1 + (uint64_t)b0 * pa.p1 * pa.regions1 * pa.cap1 * kChunk;
@@ -368,10 +413,11 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 
 // ---- pass C --------------------------------------------------------------------------------------
 // one workgroup per segment; the segment's entries sit in `n_regions` regions of `cap` chunks each
+template <bool QUERY>
 __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
                                                                  uint32_t seg_shift, const uint32_t* cur,
                                                                  const uint32_t* ent, uint32_t cap,
-                                                                 uint32_t n_regions)
+                                                                 uint32_t n_regions, const PartArgs pa)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	__shared__ uint32_t any;
@@ -411,11 +457,18 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 			const uint4 q = e4[i];
 			const uint32_t e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-			for (int c = 0; c < 4; ++c)
-				if (e[c] != kSentinel)
+			for (int c = 0; c < 4; ++c) {
+				if (e[c] == kSentinel)
+					continue;
+				if (!QUERY)
 					atomicOr(&lds[e[c] >> 5], 1u << (e[c] & 31));
+				else if (!((lds[e[c] >> 5] >> (e[c] & 31)) & 1u))
+					part_report_fail(pa, (seg << seg_shift) | e[c]);
+			}
 		}
 	}
+	if (QUERY)
+		return; // read-only sweep
 	__syncthreads();
 	for (uint32_t i = tid; i < n_vec; i += kApplyThreads)
 		g4[i] = lds4[i];
@@ -449,17 +502,17 @@ bool part_hash_fits(const HashParams& hp_in, uint32_t p0)
 	return part_hash_lds_bytes(hp, p0) <= kPartLdsBudget;
 }
 
-template <int H>
+template <int H, bool Q>
 static hipError_t launch_hash_h(const SeqArgs& a, const PartArgs& pa, unsigned blocks, size_t dyn, hipStream_t s)
 {
 	const bool pow2 = a.mod.pow2 != 0, spaced = a.hp.n_seeds > 0;
-#define BTLBF_PLAUNCH(P, S)                                                                               \
-	do {                                                                                                  \
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_kernel<H, P, S>),       \
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);          \
-		if (e != hipSuccess)                                                                              \
-			return e;                                                                                     \
-		hipLaunchKernelGGL((part_hash_kernel<H, P, S>), dim3(blocks), dim3(kPartThreads), dyn, s, a, pa); \
+#define BTLBF_PLAUNCH(P, S)                                                                                  \
+	do {                                                                                                     \
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_kernel<H, P, S, Q>),       \
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);             \
+		if (e != hipSuccess)                                                                                 \
+			return e;                                                                                        \
+		hipLaunchKernelGGL((part_hash_kernel<H, P, S, Q>), dim3(blocks), dim3(kPartThreads), dyn, s, a, pa); \
 	} while (0)
 	if (pow2 && !spaced)
 		BTLBF_PLAUNCH(true, false);
@@ -471,6 +524,22 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartArgs& pa, unsigned b
 		BTLBF_PLAUNCH(false, true);
 #undef BTLBF_PLAUNCH
 	return hipGetLastError();
+}
+
+template <bool Q>
+static hipError_t launch_hash_q(const SeqArgs& a, const PartArgs& pa, unsigned blocks, size_t dyn, hipStream_t s)
+{
+	switch (a.hp.h) {
+	case 1: return launch_hash_h<1, Q>(a, pa, blocks, dyn, s);
+	case 2: return launch_hash_h<2, Q>(a, pa, blocks, dyn, s);
+	case 3: return launch_hash_h<3, Q>(a, pa, blocks, dyn, s);
+	case 4: return launch_hash_h<4, Q>(a, pa, blocks, dyn, s);
+	case 5: return launch_hash_h<5, Q>(a, pa, blocks, dyn, s);
+	case 6: return launch_hash_h<6, Q>(a, pa, blocks, dyn, s);
+	case 7: return launch_hash_h<7, Q>(a, pa, blocks, dyn, s);
+	case 8: return launch_hash_h<8, Q>(a, pa, blocks, dyn, s);
+	default: return hipErrorInvalidValue;
+	}
 }
 
 bool part_supported_h(uint32_t h) { return h >= 1 && h <= 8; }
@@ -489,41 +558,71 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartArgs& pa, hipStream_t
 	const unsigned blocks = pa.regions0;
 	a.tiles_per_block = (a.n_tiles + blocks - 1) / blocks;
 	const size_t dyn = part_hash_lds_bytes(a.hp, pa.p0);
-	switch (a.hp.h) {
-	case 1: return launch_hash_h<1>(a, pa, blocks, dyn, s);
-	case 2: return launch_hash_h<2>(a, pa, blocks, dyn, s);
-	case 3: return launch_hash_h<3>(a, pa, blocks, dyn, s);
-	case 4: return launch_hash_h<4>(a, pa, blocks, dyn, s);
-	case 5: return launch_hash_h<5>(a, pa, blocks, dyn, s);
-	case 6: return launch_hash_h<6>(a, pa, blocks, dyn, s);
-	case 7: return launch_hash_h<7>(a, pa, blocks, dyn, s);
-	case 8: return launch_hash_h<8>(a, pa, blocks, dyn, s);
-	default: return hipErrorInvalidValue;
-	}
+	return pa.fail_count ? launch_hash_q<true>(a, pa, blocks, dyn, s) : launch_hash_q<false>(a, pa, blocks, dyn, s);
 }
 
 hipError_t launch_part_split(void* filter, const PartArgs& pa, hipStream_t s)
 {
 	const size_t dyn = part_lds_bytes(pa.p1);
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_split_kernel),
-	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+	const void* fn = pa.fail_count ? reinterpret_cast<const void*>(&part_split_kernel<true>)
+	                               : reinterpret_cast<const void*>(&part_split_kernel<false>);
+	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 	if (e != hipSuccess)
 		return e;
-	hipLaunchKernelGGL(part_split_kernel, dim3(pa.p0 * pa.regions1), dim3(kPartThreads), dyn, s, filter, pa);
+	if (pa.fail_count)
+		hipLaunchKernelGGL(part_split_kernel<true>, dim3(pa.p0 * pa.regions1), dim3(kPartThreads), dyn, s, filter, pa);
+	else
+		hipLaunchKernelGGL(part_split_kernel<false>, dim3(pa.p0 * pa.regions1), dim3(kPartThreads), dyn, s, filter, pa);
 	return hipGetLastError();
 }
 
-hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs& pa, hipStream_t s)
+hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs& pa, int test_only, hipStream_t s)
 {
 	const size_t dyn = (size_t)1 << (pa.seg_shift - 3);
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_apply_kernel),
-	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+	const void* fn = test_only ? reinterpret_cast<const void*>(&part_apply_kernel<true>)
+	                           : reinterpret_cast<const void*>(&part_apply_kernel<false>);
+	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 	if (e != hipSuccess)
 		return e;
 	const bool two = pa.levels == 2;
-	hipLaunchKernelGGL(part_apply_kernel, dim3((unsigned)pa.n_seg), dim3(kApplyThreads), dyn, s,
-	                   static_cast<uint8_t*>(filter), local_bytes, pa.seg_shift, two ? pa.cur1 : pa.cur0,
-	                   two ? pa.out1 : pa.out0, two ? pa.cap1 : pa.cap0, two ? pa.regions1 : pa.regions0);
+	const uint32_t* cur = two ? pa.cur1 : pa.cur0;
+	const uint32_t* ent = two ? pa.out1 : pa.out0;
+	const uint32_t cap = two ? pa.cap1 : pa.cap0, regions = two ? pa.regions1 : pa.regions0;
+	if (test_only)
+		hipLaunchKernelGGL(part_apply_kernel<true>, dim3((unsigned)pa.n_seg), dim3(kApplyThreads), dyn, s,
+		                   static_cast<uint8_t*>(filter), local_bytes, pa.seg_shift, cur, ent, cap, regions, pa);
+	else
+		hipLaunchKernelGGL(part_apply_kernel<false>, dim3((unsigned)pa.n_seg), dim3(kApplyThreads), dyn, s,
+		                   static_cast<uint8_t*>(filter), local_bytes, pa.seg_shift, cur, ent, cap, regions, pa);
+	return hipGetLastError();
+}
+
+// ---- failed-position set (partitioned query, resolve step) ----------------------------------------
+// open-addressing table of 64-bit keys (position + 1; 0 = empty), linear probing
+__global__ __launch_bounds__(256) void failset_build_kernel(const uint64_t* list, uint64_t n,
+                                                           unsigned long long* table, uint64_t mask)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const unsigned long long key = list[i] + 1;
+		uint64_t slot = mix64(key) & mask;
+		for (;;) {
+			const unsigned long long prev = atomicCAS(&table[slot], 0ull, key);
+			if (prev == 0ull || prev == key)
+				break;
+			slot = (slot + 1) & mask;
+		}
+	}
+}
+
+hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t* table, uint64_t mask, hipStream_t s)
+{
+	if (n == 0)
+		return hipSuccess;
+	uint64_t blocks = (n + 255) / 256;
+	if (blocks > 2048)
+		blocks = 2048;
+	hipLaunchKernelGGL(failset_build_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fail_list, n,
+	                   reinterpret_cast<unsigned long long*>(table), mask);
 	return hipGetLastError();
 }
 

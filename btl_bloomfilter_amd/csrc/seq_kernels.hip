@@ -114,6 +114,26 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 					}
 					hit_mask |= all << w;
 				}
+			} else if (OP == OP_BF_RESOLVE) {
+				// partitioned query, second step: a.buckets is the failed-position hash set
+				// (key = position + 1, 0 = empty, linear probing), a.bucket_cap its index mask
+				if (ok) {
+					const unsigned long long* table = reinterpret_cast<const unsigned long long*>(a.buckets);
+					uint32_t all = 1;
+					for (uint32_t i = 0; i < h; ++i) {
+						const unsigned long long key = reduce_mod<POW2>(wh.at(i), a.mod) + 1;
+						uint64_t slot = mix64(key) & a.bucket_cap;
+						for (;;) {
+							const unsigned long long v = table[slot];
+							if (v == key)
+								all = 0;
+							if (v == key || v == 0ull)
+								break;
+							slot = (slot + 1) & a.bucket_cap;
+						}
+					}
+					hit_mask |= all << w;
+				}
 			} else if (OP == OP_CBF_QUERY) {
 				const uint8_t* ctr = static_cast<const uint8_t*>(a.filter);
 				uint32_t mn = 0xff;
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 
 		// ---- results ----
 		const uint64_t ob = (g0 >> 3) + tid;
-		if (OP == OP_BF_CONTAINS || OP == OP_BF_INSERT_CHECK || OP == OP_CBF_QUERY) {
+		if (OP == OP_BF_CONTAINS || OP == OP_BF_INSERT_CHECK || OP == OP_CBF_QUERY || OP == OP_BF_RESOLVE) {
 			if (a.hit_bits && ob < out_bytes)
 				a.hit_bits[ob] = (uint8_t)hit_mask;
 		}
@@ -280,6 +300,7 @@ hipError_t launch_seq_op(int op, const SeqArgs& a_in, hipStream_t s)
 	case OP_CBF_QUERY: return launch_one<OP_CBF_QUERY>(a, s, grid, dyn);
 	case OP_HASH_ONLY: return launch_one<OP_HASH_ONLY>(a, s, grid, dyn);
 	case OP_POSITIONS: return launch_one<OP_POSITIONS>(a, s, grid, dyn);
+	case OP_BF_RESOLVE: return launch_one<OP_BF_RESOLVE>(a, s, grid, dyn);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -155,6 +155,11 @@ class _Filter:
         m = {"auto": 0, "direct": 1, "partitioned": 2}[mode] if isinstance(mode, str) else int(mode)
         check(self._L.btlbf_set_insert_mode(self._h, m, int(scratch_bytes)))
 
+    def setQueryMode(self, mode):
+        """'auto' | 'direct' | 'partitioned' (see btlbf_set_query_mode)"""
+        m = {"auto": 0, "direct": 1, "partitioned": 2}[mode] if isinstance(mode, str) else int(mode)
+        check(self._L.btlbf_set_query_mode(self._h, m))
+
     def setSpacedSeeds(self, seeds, h2=1):
         arr = (C.c_char_p * len(seeds))(*[s.encode() if isinstance(s, str) else s for s in seeds])
         check(self._L.btlbf_set_spaced_seeds(self._h, arr, len(seeds), h2))

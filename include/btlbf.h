@@ -125,6 +125,11 @@ int btlbf_download(const btlbf_filter* f, void* host_dst, uint64_t offset, uint6
  * variable BTLBF_INSERT_MODE=direct|partitioned. */
 enum { BTLBF_INSERT_AUTO = 0, BTLBF_INSERT_DIRECT = 1, BTLBF_INSERT_PARTITIONED = 2 };
 int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch_bytes);
+/* Same choice for btlbf_contains_seqs on a bit filter.  PARTITIONED tests the partitioned positions
+ * against each segment in LDS and keeps the few positions found clear; it pays off when nearly
+ * every k-mer hits (a batch with many misses is redone by the direct gather kernel).  AUTO samples
+ * the batch first.  Results are identical in every mode.  Environment: BTLBF_QUERY_MODE. */
+int btlbf_set_query_mode(btlbf_filter* f, int mode);
 
 /* Use spaced-seed hashing (stHashIterator, vendor/stHashIterator.hpp:23-33,53-57) for every
  * sequence-buffer call on this filter: `seeds` are n_seeds strings of length kmer_size, '1' =
@@ -205,7 +210,7 @@ int btlbf_test_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n,
                          void* stream);
 int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, unsigned hash_num,
                       uint64_t* hit_bits, int device, void* stream);
-/* number of set bits in a device buffer (e.g. a hit bitmap); synchronises the stream */
+/* number of set bits in a device buffer of nbytes (multiple of 8, e.g. a hit bitmap); synchronises the stream */
 int btlbf_popcount_bits(const void* dev_buf, uint64_t nbytes, uint64_t* out, int device, void* stream);
 
 /* ---- support ------------------------------------------------------------------------------------

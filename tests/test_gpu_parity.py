@@ -517,3 +517,45 @@ def test_partitioned_spaced_seeds_and_shard(bf):
         s.insertSeqs(reads, read_len=L)
         n = bits // 8 // 4
         assert (s.download() == body[idx * n:(idx + 1) * n]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# partitioned contains(): test in LDS + failed-position set; must equal the direct gather kernel
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bits,miss_reads", [(1 << 30, 0), (1 << 30, 3), (1 << 30, 4000), (3 << 22, 50), (1 << 33, 7)])
+def test_partitioned_query_equals_direct(bf, bits, miss_reads):
+    import torch
+
+    k, h, L, n = 31, 4, 150, 40000
+    reads = bf.synth_reads_device(42, 0, n, L)
+    flt = bf.BloomFilter(bits, h, k)
+    flt.insertSeqs(reads, read_len=L)
+    # query = inserted reads with a few foreign reads spliced in (all hits / few misses / too many
+    # misses for the fail list -> falls back to the direct kernel per batch)
+    q = reads.clone()
+    if miss_reads:
+        other = bf.synth_reads_device(43, 0, miss_reads, L)
+        idx = torch.arange(miss_reads, device="cuda") * (n // miss_reads)
+        q.view(n, L)[idx] = other.view(miss_reads, L)
+    q[12345] = ord("N")  # an unclean window or 31
+    out = {}
+    for mode in ("direct", "partitioned"):
+        flt.setQueryMode(mode)
+        hit, valid, cnt = flt.containsSeqs(q, read_len=L, want_valid=True, want_counts=True)
+        torch.cuda.synchronize()
+        out[mode] = (hit.cpu().numpy(), valid.cpu().numpy(), cnt.cpu().tolist())
+    assert (out["direct"][1] == out["partitioned"][1]).all()
+    assert (out["direct"][0] == out["partitioned"][0]).all()
+    assert out["direct"][2] == out["partitioned"][2]
+    assert out["direct"][2][0] == n * 120 - 31
+    if miss_reads == 0:
+        assert out["partitioned"][2][1] == out["partitioned"][2][0]
+    else:
+        assert out["partitioned"][2][1] < out["partitioned"][2][0]
+    # counts-only call (no bitmaps requested) and auto mode agree too
+    flt.setQueryMode("partitioned")
+    _, _, cnt = flt.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    assert cnt.cpu().tolist() == out["direct"][2]
+    flt.setQueryMode("auto")
+    hit, _, cnt = flt.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    assert cnt.cpu().tolist() == out["direct"][2] and (hit.cpu().numpy() == out["direct"][0]).all()

@@ -15,6 +15,7 @@ def main():
     mode = sys.argv[3] if len(sys.argv) > 3 else "auto"
     f = m.BloomFilter(1 << lg, h, k)
     f.setInsertMode(mode)
+    f.setQueryMode(sys.argv[4] if len(sys.argv) > 4 else "auto")
     reads = m.synth_reads_device(42, 0, n_reads, L)
     q = m.synth_reads_device(43, 0, n_reads, L)
     torch.cuda.synchronize()
