@@ -13,6 +13,9 @@ INCREMENT_MIN, INCREMENT_ALL = 0, 1
 ORDER_PARALLEL, ORDER_SERIAL = 0, 1
 OK, EINVAL, ENOMEM, EIO, EFORMAT, EHIP = range(6)
 INSERT_AUTO, INSERT_DIRECT, INSERT_PARTITIONED = 0, 1, 2
+PROF_SLOTS = 10
+PROF_NAMES = ["insert_direct", "query_direct", "insert_hash", "insert_split", "insert_apply", "query_hash",
+              "query_split", "query_test", "query_resolve", "other"]
 
 
 class Layout(C.Structure):
@@ -57,6 +60,8 @@ _PROTOS = {
     "btlbf_upload": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     "btlbf_download": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     "btlbf_set_insert_mode": (C.c_int, [_P, C.c_int, C.c_uint64]),
+    "btlbf_set_profiling": (C.c_int, [_P, C.c_int]),
+    "btlbf_get_profile": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint), C.c_int]),
     "btlbf_set_query_mode": (C.c_int, [_P, C.c_int]),
     "btlbf_set_spaced_seeds": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_uint, C.c_uint]),
     "btlbf_insert_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_int, C.c_int, C.c_int, _P]),

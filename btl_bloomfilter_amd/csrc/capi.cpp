@@ -82,9 +82,43 @@ struct btlbf_filter {
 	void* d_part = nullptr;
 	uint64_t part_bytes = 0;
 	uint64_t part_budget = 0; // 0 = derive from free HBM
+	// optional per-kernel timing with HIP events on the launch stream (btlbf_set_profiling)
+	bool profiling = false;
+	struct Span {
+		int slot;
+		hipEvent_t e0, e1;
+	};
+	std::vector<Span> spans;
+	double prof_ms[BTLBF_PROF_SLOTS] = {0};
+	unsigned prof_calls[BTLBF_PROF_SLOTS] = {0};
 };
 
 namespace {
+
+// times one kernel launch with a pair of events when profiling is on
+struct ProfSpan {
+	btlbf_filter* f;
+	hipStream_t s;
+	int idx = -1;
+	ProfSpan(btlbf_filter* f_, int slot, hipStream_t s_)
+	  : f(f_)
+	  , s(s_)
+	{
+		if (!f->profiling)
+			return;
+		btlbf_filter::Span sp{slot, nullptr, nullptr};
+		if (hipEventCreate(&sp.e0) != hipSuccess || hipEventCreate(&sp.e1) != hipSuccess)
+			return;
+		(void)hipEventRecord(sp.e0, s);
+		f->spans.push_back(sp);
+		idx = (int)f->spans.size() - 1;
+	}
+	~ProfSpan()
+	{
+		if (idx >= 0)
+			(void)hipEventRecord(f->spans[idx].e1, s);
+	}
+};
 
 struct DeviceGuard {
 	int prev = -1;
@@ -541,6 +575,40 @@ extern "C" int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch
 	return BTLBF_OK;
 }
 
+extern "C" int btlbf_set_profiling(btlbf_filter* f, int on)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	f->profiling = on != 0;
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_get_profile(btlbf_filter* f, double* ms, unsigned* calls, int reset)
+{
+	if (!f || !ms || !calls)
+		return fail(BTLBF_EINVAL, "null argument");
+	DeviceGuard g(f->device);
+	for (auto& sp : f->spans) {
+		float t = 0;
+		if (hipEventSynchronize(sp.e1) == hipSuccess && hipEventElapsedTime(&t, sp.e0, sp.e1) == hipSuccess) {
+			f->prof_ms[sp.slot] += t;
+			f->prof_calls[sp.slot] += 1;
+		}
+		(void)hipEventDestroy(sp.e0);
+		(void)hipEventDestroy(sp.e1);
+	}
+	f->spans.clear();
+	for (int i = 0; i < BTLBF_PROF_SLOTS; ++i) {
+		ms[i] = f->prof_ms[i];
+		calls[i] = f->prof_calls[i];
+		if (reset) {
+			f->prof_ms[i] = 0;
+			f->prof_calls[i] = 0;
+		}
+	}
+	return BTLBF_OK;
+}
+
 extern "C" int btlbf_set_query_mode(btlbf_filter* f, int mode)
 {
 	if (!f || mode < BTLBF_INSERT_AUTO || mode > BTLBF_INSERT_PARTITIONED)
@@ -873,8 +941,10 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 				HIP_TRY(hipStreamSynchronize(s)); // tmp_hit is freed on return
 		}
 	}
-	if (!done)
+	if (!done) {
+		ProfSpan ps(f, op == OP_BF_CONTAINS ? BTLBF_PROF_QUERY_DIRECT : BTLBF_PROF_OTHER, s);
 		HIP_TRY(launch_seq_op(op, a, s));
+	}
 	if ((rc = ob_hit.finish(s)) || (rc = ob_valid.finish(s)) || (rc = ob_cnt.finish(s)) ||
 	    (rc = ob_min.finish(s)))
 		return rc;
@@ -1040,10 +1110,18 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 		SeqArgs a = base;
 		a.first_tile = t0;
 		a.n_tiles = std::min<uint64_t>(pl.tiles_per_batch, total_tiles - t0);
-		HIP_TRY(launch_part_hash(a, pl.pa, s)); // every writer publishes all of its region counts
-		if (pl.pa.levels == 2)
+		{
+			ProfSpan ps(f, BTLBF_PROF_INSERT_HASH, s);
+			HIP_TRY(launch_part_hash(a, pl.pa, s)); // every writer publishes all of its region counts
+		}
+		if (pl.pa.levels == 2) {
+			ProfSpan ps(f, BTLBF_PROF_INSERT_SPLIT, s);
 			HIP_TRY(launch_part_split(f->d_data, pl.pa, s));
-		HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, 0, s));
+		}
+		{
+			ProfSpan ps(f, BTLBF_PROF_INSERT_APPLY, s);
+			HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, 0, s));
+		}
 	}
 	*done = true;
 	return BTLBF_OK;
@@ -1078,10 +1156,18 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 		a.valid_bits = valid_bits;
 		a.counts = counts; // pass A adds the clean-window count to counts[0]
 		HIP_TRY(hipMemsetAsync(pl.pa.fail_count, 0, 8, s));
-		HIP_TRY(launch_part_hash(a, pl.pa, s));
-		if (pl.pa.levels == 2)
+		{
+			ProfSpan ps(f, BTLBF_PROF_QUERY_HASH, s);
+			HIP_TRY(launch_part_hash(a, pl.pa, s));
+		}
+		if (pl.pa.levels == 2) {
+			ProfSpan ps(f, BTLBF_PROF_QUERY_SPLIT, s);
 			HIP_TRY(launch_part_split(f->d_data, pl.pa, s));
-		HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, 1, s));
+		}
+		{
+			ProfSpan ps(f, BTLBF_PROF_QUERY_TEST, s);
+			HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, 1, s));
+		}
 		unsigned long long n_fail = 0;
 		HIP_TRY(hipMemcpyAsync(&n_fail, pl.pa.fail_count, 8, hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
@@ -1094,6 +1180,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 		d.hit_bits = hit_bits;
 		d.valid_bits = nullptr;
 		d.counts = nullptr;
+		ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
 		if (n_fail > kFailCap) {
 			HIP_TRY(launch_seq_op(OP_BF_CONTAINS, d, s));
 		} else {
@@ -1199,7 +1286,10 @@ extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
 			return BTLBF_OK;
 		}
 	}
-	HIP_TRY(launch_seq_op(kop, a, s));
+	{
+		ProfSpan ps(f, kop == OP_BF_INSERT ? BTLBF_PROF_INSERT_DIRECT : BTLBF_PROF_OTHER, s);
+		HIP_TRY(launch_seq_op(kop, a, s));
+	}
 	if (mem == BTLBF_HOST)
 		HIP_TRY(hipStreamSynchronize(s));
 	return BTLBF_OK;

@@ -155,6 +155,16 @@ class _Filter:
         m = {"auto": 0, "direct": 1, "partitioned": 2}[mode] if isinstance(mode, str) else int(mode)
         check(self._L.btlbf_set_insert_mode(self._h, m, int(scratch_bytes)))
 
+    def setProfiling(self, on=True):
+        check(self._L.btlbf_set_profiling(self._h, int(bool(on))))
+
+    def getProfile(self, reset=True):
+        """{kernel slot name: (milliseconds, launches)} measured with HIP events on the launch stream"""
+        ms = (C.c_double * _lib.PROF_SLOTS)()
+        calls = (C.c_uint * _lib.PROF_SLOTS)()
+        check(self._L.btlbf_get_profile(self._h, ms, calls, int(bool(reset))))
+        return {n: (ms[i], calls[i]) for i, n in enumerate(_lib.PROF_NAMES) if calls[i]}
+
     def setQueryMode(self, mode):
         """'auto' | 'direct' | 'partitioned' (see btlbf_set_query_mode)"""
         m = {"auto": 0, "direct": 1, "partitioned": 2}[mode] if isinstance(mode, str) else int(mode)

@@ -131,6 +131,25 @@ int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch_bytes);
  * the batch first.  Results are identical in every mode.  Environment: BTLBF_QUERY_MODE. */
 int btlbf_set_query_mode(btlbf_filter* f, int mode);
 
+/* Per-kernel timing for measurement harnesses: when on, every kernel the sequence calls launch is
+ * bracketed by HIP events on the launch stream.  btlbf_get_profile synchronises those events and
+ * returns accumulated milliseconds and launch counts per slot (arrays of BTLBF_PROF_SLOTS). */
+enum {
+	BTLBF_PROF_INSERT_DIRECT = 0, /* seq_kernel<OP_BF_INSERT>: fused ntHash + atomicOr */
+	BTLBF_PROF_QUERY_DIRECT = 1,  /* seq_kernel<OP_BF_CONTAINS>: fused ntHash + gather */
+	BTLBF_PROF_INSERT_HASH = 2,   /* part_hash_kernel (pass A) */
+	BTLBF_PROF_INSERT_SPLIT = 3,  /* part_split_kernel (pass B) */
+	BTLBF_PROF_INSERT_APPLY = 4,  /* part_apply_kernel (pass C, OR in LDS) */
+	BTLBF_PROF_QUERY_HASH = 5,
+	BTLBF_PROF_QUERY_SPLIT = 6,
+	BTLBF_PROF_QUERY_TEST = 7,    /* part_apply_kernel<QUERY> (pass C, test in LDS) */
+	BTLBF_PROF_QUERY_RESOLVE = 8, /* failed-position set + resolve pass, or direct redo of a batch */
+	BTLBF_PROF_OTHER = 9,
+	BTLBF_PROF_SLOTS = 10
+};
+int btlbf_set_profiling(btlbf_filter* f, int on);
+int btlbf_get_profile(btlbf_filter* f, double* ms, unsigned* calls, int reset);
+
 /* Use spaced-seed hashing (stHashIterator, vendor/stHashIterator.hpp:23-33,53-57) for every
  * sequence-buffer call on this filter: `seeds` are n_seeds strings of length kmer_size, '1' =
  * care; hash_num must equal n_seeds*h2.  Without this call sequences are hashed like
