@@ -78,6 +78,14 @@ _PROTOS = {
     "btlbf_filtered_popcount": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "btlbf_positions_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_uint, _P, _P, C.c_uint64, _P, _P,
                                        _P]),
+    "btlbf_route_plan": (C.c_int, [_P, C.c_uint64, C.POINTER(Layout), C.c_uint, C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64)]),
+    "btlbf_route_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_uint64, C.c_uint, C.c_int, _P, _P, _P, _P,
+                                   _P, _P, C.c_uint64, _P, _P]),
+    "btlbf_apply_routed": (C.c_int, [_P, _P, _P, C.c_uint, C.c_uint64, C.POINTER(Layout), C.c_uint, C.c_int, _P,
+                                     C.c_uint64, _P, _P]),
+    "btlbf_apply_spill": (C.c_int, [_P, _P, C.c_uint64, C.c_int, _P, C.c_uint64, _P, _P]),
+    "btlbf_resolve_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), _P, C.c_uint64, _P, _P]),
     "btlbf_popcount_bits": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64), C.c_int, _P]),
     "btlbf_insert_positions": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "btlbf_test_positions": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),

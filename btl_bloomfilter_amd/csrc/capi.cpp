@@ -957,76 +957,169 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 
 namespace {
 
-// Geometry, capacities and batch size of the partitioned insert for `total_tiles` tiles of
-// part_tile_windows() windows.  Returns false if the filter shape is not
-// supported (then the direct kernel is used).
-struct PartPlan {
-	PartArgs pa;
-	uint64_t tiles_per_batch;
-	uint64_t bytes_cur0, bytes_cur1, bytes_out0, bytes_out1, bytes_total;
-};
-
 // partitioned query: room for the failed positions of one batch and their hash set
-static constexpr uint64_t kFailCap = 4ull << 20;             // entries
-static constexpr uint64_t kFailTableSlots = 2 * kFailCap;    // power of two
+static constexpr uint64_t kFailCap = 4ull << 20;          // entries
+static constexpr uint64_t kFailTableSlots = 2 * kFailCap; // power of two
 static constexpr uint64_t kFailBytes = 256 + kFailCap * 8 + kFailTableSlots * 8;
 
+// one partition level: bins of 2^shift positions, written as regions of `cap` chunks
+struct PartLevel {
+	uint32_t bins = 0;    // bins at this level (covering the local array)
+	uint32_t P = 0;       // bins per writer block (pass A: all of them; split: the fan-out)
+	uint32_t regions = 0; // writers per bin
+	uint32_t cap = 0;     // chunks per region
+	uint32_t shift = 0;   // log2(positions per bin)
+	uint64_t cnt_bytes = 0, ent_bytes = 0;
+	uint32_t* cnt = nullptr;
+	uint32_t* ent = nullptr;
+	PartOut out() const { return PartOut{P, regions, cap, cnt, ent}; }
+	PartIn in() const { return PartIn{1, bins, regions, cap, cnt, ent}; }
+};
+
+struct PartPlan {
+	uint32_t seg_shift = 19;
+	uint64_t n_seg = 0;
+	int n_levels = 0; // lv[0] = pass A output (or the exchanged data), lv[1..] = split outputs
+	PartLevel lv[3];
+	uint64_t tiles_per_batch = 0;
+	uint64_t bytes_total = 0;
+};
+
 // chunks a region needs for `mean_entries` expected entries (Poisson: mean + 8 sigma) plus the
-// partially filled chunks flushed at kernel end
+// partially filled chunk flushed at kernel end
 uint32_t chunks_for(double mean_entries, uint32_t tail_chunks)
 {
 	const double m = mean_entries + 8.0 * std::sqrt(mean_entries + 1.0) + 32.0;
 	return (uint32_t)std::min<double>(4.0e9, std::ceil(m / 32.0)) + tail_chunks;
 }
 
-bool plan_partition(const btlbf_filter* f, uint64_t total_tiles, double probes_per_tile, unsigned blocks_a,
-                    uint64_t budget, uint64_t extra_bytes, PartPlan& pl)
+unsigned ceil_log2(uint64_t x)
 {
-	const uint64_t mloc = f->mod.shard_len;
-	PartArgs& pa = pl.pa;
-	memset(&pa, 0, sizeof pa);
-	pa.seg_shift = 19;
+	unsigned b = 0;
+	while ((1ull << b) < x)
+		++b;
+	return b;
+}
+
+bool plan_segments(uint64_t mloc, PartPlan& pl)
+{
+	pl.seg_shift = 19;
 	if (((mloc + (1ull << 19) - 1) >> 19) > 1024ull * 1024)
-		pa.seg_shift = 20;
-	pa.n_seg = (mloc + (1ull << pa.seg_shift) - 1) >> pa.seg_shift;
-	if (pa.n_seg > 1024ull * 1024)
+		pl.seg_shift = 20;
+	pl.n_seg = (mloc + (1ull << pl.seg_shift) - 1) >> pl.seg_shift;
+	return pl.n_seg <= 1024ull * 1024;
+}
+
+// append the split levels that take bins of 2^lv[0].shift positions down to segments
+bool plan_splits(PartPlan& pl, uint32_t regions_in_total)
+{
+	const uint32_t rb = pl.lv[0].shift - pl.seg_shift;
+	pl.n_levels = 1;
+	if (rb == 0)
+		return true;
+	if (rb > 20)
 		return false;
-	if (pa.n_seg <= 1024) {
-		pa.levels = 1;
-		pa.p0 = (uint32_t)pa.n_seg;
-		pa.p1 = 1;
-		pa.bin_shift = pa.seg_shift;
-	} else { // split the segment index bits evenly between the two levels
-		unsigned bits = 0;
-		while ((1ull << bits) < pa.n_seg)
-			++bits;
-		const unsigned b1 = bits / 2;
-		pa.levels = 2;
-		pa.p1 = 1u << b1;
-		pa.p0 = (uint32_t)((pa.n_seg + pa.p1 - 1) >> b1);
-		pa.bin_shift = pa.seg_shift + b1;
+	const uint32_t fan[2] = {rb <= 10 ? rb : rb - rb / 2, rb <= 10 ? 0 : rb / 2};
+	uint32_t regions_in = regions_in_total;
+	for (int j = 0; j < 2 && fan[j]; ++j) {
+		PartLevel& in = pl.lv[pl.n_levels - 1];
+		PartLevel& o = pl.lv[pl.n_levels];
+		o.P = 1u << fan[j];
+		o.bins = in.bins * o.P;
+		o.shift = in.shift - fan[j];
+		o.regions = std::max(1u, std::min(regions_in, (512 + in.bins - 1) / in.bins));
+		regions_in = o.regions;
+		++pl.n_levels;
 	}
-	pa.regions0 = blocks_a;
-	pa.regions1 = pa.levels == 2 ? std::max(1u, std::min(blocks_a, (512 + pa.p0 - 1) / pa.p0)) : 0;
-	uint64_t tiles = total_tiles;
-	for (int iter = 0; iter < 64; ++iter) {
-		const double nb = (double)tiles * probes_per_tile;
-		pa.cap0 = chunks_for(nb / ((double)pa.p0 * pa.regions0), 1);
-		pa.cap1 = pa.levels == 2 ? chunks_for(nb / ((double)pa.p0 * pa.p1 * pa.regions1), 1) : 0;
-		pl.bytes_cur0 = ((uint64_t)pa.p0 * pa.regions0 * 4 + 255) / 256 * 256;
-		pl.bytes_cur1 = pa.levels == 2 ? ((uint64_t)pa.p0 * pa.p1 * pa.regions1 * 4 + 255) / 256 * 256 : 0;
-		pl.bytes_out0 = (uint64_t)pa.p0 * pa.regions0 * pa.cap0 * 128;
-		pl.bytes_out1 = pa.levels == 2 ? (uint64_t)pa.p0 * pa.p1 * pa.regions1 * pa.cap1 * 128 : 0;
-		pl.bytes_total = pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0 + pl.bytes_out1 + extra_bytes;
-		if (pl.bytes_total <= budget || tiles <= 1)
-			break;
-		// shrink the batch in proportion (plus a little) and try again
-		const double ratio = (double)budget / (double)pl.bytes_total;
-		uint64_t nt = (uint64_t)((double)tiles * ratio * 0.95);
-		tiles = nt >= tiles ? tiles - 1 : (nt ? nt : 1);
+	return true;
+}
+
+// capacities + byte sizes for `entries` expected entries in the whole batch
+void plan_caps(PartPlan& pl, double entries, int first_level)
+{
+	pl.bytes_total = 0;
+	for (int j = first_level; j < pl.n_levels; ++j) {
+		PartLevel& l = pl.lv[j];
+		// the last level has n_seg useful bins although bins may be rounded up
+		const double useful = j == pl.n_levels - 1 ? (double)std::min<uint64_t>(pl.n_seg, l.bins) : (double)l.bins;
+		l.cap = chunks_for(entries / (useful * l.regions), 1);
+		l.cnt_bytes = ((uint64_t)l.bins * l.regions * 4 + 255) / 256 * 256;
+		l.ent_bytes = (uint64_t)l.bins * l.regions * l.cap * 128;
+		pl.bytes_total += l.cnt_bytes + l.ent_bytes;
 	}
-	pl.tiles_per_batch = tiles;
-	return pl.bytes_total <= budget;
+}
+
+uint8_t* carve_levels(PartPlan& pl, uint8_t* p, int first_level)
+{
+	for (int j = first_level; j < pl.n_levels; ++j) {
+		pl.lv[j].cnt = reinterpret_cast<uint32_t*>(p);
+		p += pl.lv[j].cnt_bytes;
+		pl.lv[j].ent = reinterpret_cast<uint32_t*>(p);
+		p += pl.lv[j].ent_bytes;
+	}
+	return p;
+}
+
+int ensure_scratch(btlbf_filter* f, uint64_t bytes, bool* ok)
+{
+	*ok = true;
+	if (bytes <= f->part_bytes)
+		return BTLBF_OK;
+	(void)hipFree(f->d_part);
+	f->d_part = nullptr;
+	f->part_bytes = 0;
+	hipError_t e = hipMalloc(&f->d_part, bytes);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		*ok = false; // no room for scratch: the caller falls back to the direct kernels
+		return BTLBF_OK;
+	}
+	f->part_bytes = bytes;
+	return BTLBF_OK;
+}
+
+uint64_t scratch_budget(btlbf_filter* f)
+{
+	if (f->part_budget)
+		return f->part_budget;
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+		return 0;
+	return (uint64_t)((double)(free_b + f->part_bytes) * 0.80);
+}
+
+unsigned cu_count(int device)
+{
+	int cus = 256;
+	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+	return (unsigned)cus;
+}
+
+double probes_per_tile(const btlbf_filter* f, const LayoutParams& lay)
+{
+	double frac = 1.0;
+	if (!lay.starts && lay.read_len) {
+		const double L = lay.read_len;
+		frac = L >= f->hp.k ? (L - f->hp.k + 1) / L : 0.0;
+	}
+	return (double)part_tile_windows() * f->hp.h * frac + 1.0;
+}
+
+// run the split levels lv[1..] over the level-0 data `in0`, then the apply / test pass
+int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, int query, hipStream_t s)
+{
+	PartIn in = in0;
+	uint32_t bins_in = pl.lv[0].bins, in_shift = pl.lv[0].shift;
+	for (int j = 1; j < pl.n_levels; ++j) {
+		ProfSpan ps(f, query ? BTLBF_PROF_QUERY_SPLIT : BTLBF_PROF_INSERT_SPLIT, s);
+		HIP_TRY(launch_part_split(f->d_data, in, bins_in, pl.lv[j].out(), pl.lv[j].shift, in_shift, sd, query, s));
+		in = pl.lv[j].in();
+		bins_in = pl.lv[j].bins;
+		in_shift = pl.lv[j].shift;
+	}
+	ProfSpan ps(f, query ? BTLBF_PROF_QUERY_TEST : BTLBF_PROF_INSERT_APPLY, s);
+	HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.seg_shift, pl.n_seg, in, sd, query, s));
+	return BTLBF_OK;
 }
 
 // decide between the direct (atomicOr per probe) and the partitioned insert
@@ -1045,55 +1138,48 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len)
 	return probes >= 0.02 * (double)f->local_bytes && probes >= 4.0e6;
 }
 
-// plan + (re)allocate the scratch; *ok = false means "not applicable, use the direct kernel"
+// plan the single-GPU pipeline for a buffer and (re)allocate the scratch;
+// *ok = false means "not applicable, use the direct kernel"
 int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, PartPlan& pl, uint64_t* total_tiles,
-                 bool* ok)
+                 uint8_t** extra, bool* ok)
 {
 	*ok = false;
 	const uint64_t tile_w = (uint64_t)part_tile_windows();
 	*total_tiles = (base.len + tile_w - 1) / tile_w;
-	int cus = 256;
-	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, f->device);
-	const unsigned blocks_a = (unsigned)cus; // one workgroup per CU (LDS-bound)
-	double frac = 1.0;
-	if (!base.layout.starts && base.layout.read_len) {
-		const double L = base.layout.read_len;
-		frac = L >= f->hp.k ? (L - f->hp.k + 1) / L : 0.0;
-	}
-	const double probes_per_tile = (double)tile_w * f->hp.h * frac + 1.0;
-	uint64_t budget = f->part_budget;
-	if (budget == 0) {
-		size_t free_b = 0, total_b = 0;
-		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-		budget = (uint64_t)((double)(free_b + f->part_bytes) * 0.80);
-	}
-	if (!plan_partition(f, *total_tiles, probes_per_tile, blocks_a, budget, extra_bytes, pl))
+	if (!plan_segments(f->mod.shard_len, pl))
 		return BTLBF_OK;
-	if (!part_hash_fits(f->hp, pl.pa.p0))
+	PartLevel& l0 = pl.lv[0];
+	if (pl.n_seg <= 1024) {
+		l0.bins = (uint32_t)pl.n_seg;
+		l0.shift = pl.seg_shift;
+	} else { // split the segment index bits evenly between pass A and pass B
+		const unsigned b1 = ceil_log2(pl.n_seg) / 2;
+		l0.shift = pl.seg_shift + b1;
+		l0.bins = (uint32_t)((pl.n_seg + (1ull << b1) - 1) >> b1);
+	}
+	l0.P = l0.bins;
+	l0.regions = cu_count(f->device); // one pass-A workgroup per CU (LDS-bound)
+	if (!plan_splits(pl, l0.regions) || !part_hash_fits(f->hp, l0.P))
 		return BTLBF_OK;
-	if (pl.bytes_total > f->part_bytes) {
-		(void)hipFree(f->d_part);
-		f->d_part = nullptr;
-		f->part_bytes = 0;
-		hipError_t e = hipMalloc(&f->d_part, pl.bytes_total);
-		if (e != hipSuccess) {
-			(void)hipGetLastError();
-			return BTLBF_OK; // no room for scratch: direct kernel
-		}
-		f->part_bytes = pl.bytes_total;
+	const uint64_t budget = scratch_budget(f);
+	const double ppt = probes_per_tile(f, base.layout);
+	uint64_t tiles = *total_tiles;
+	for (int iter = 0; iter < 64; ++iter) {
+		plan_caps(pl, (double)tiles * ppt, 0);
+		pl.bytes_total += extra_bytes;
+		if (pl.bytes_total <= budget || tiles <= 1)
+			break;
+		const double ratio = (double)budget / (double)pl.bytes_total;
+		const uint64_t nt = (uint64_t)((double)tiles * ratio * 0.95);
+		tiles = nt >= tiles ? tiles - 1 : (nt ? nt : 1);
 	}
-	uint8_t* p = static_cast<uint8_t*>(f->d_part);
-	pl.pa.cur0 = reinterpret_cast<uint32_t*>(p);
-	pl.pa.cur1 = reinterpret_cast<uint32_t*>(p + pl.bytes_cur0);
-	pl.pa.out0 = reinterpret_cast<uint32_t*>(p + pl.bytes_cur0 + pl.bytes_cur1);
-	pl.pa.out1 = reinterpret_cast<uint32_t*>(p + pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0);
-	if (extra_bytes) {
-		uint8_t* x = p + pl.bytes_cur0 + pl.bytes_cur1 + pl.bytes_out0 + pl.bytes_out1;
-		pl.pa.fail_count = reinterpret_cast<unsigned long long*>(x);
-		pl.pa.fail_list = reinterpret_cast<uint64_t*>(x + 256);
-		pl.pa.fail_cap = kFailCap;
-	}
-	*ok = true;
+	if (pl.bytes_total > budget)
+		return BTLBF_OK;
+	pl.tiles_per_batch = tiles;
+	int rc = ensure_scratch(f, pl.bytes_total, ok);
+	if (rc || !*ok)
+		return rc;
+	*extra = carve_levels(pl, static_cast<uint8_t*>(f->d_part), 0);
 	return BTLBF_OK;
 }
 
@@ -1102,32 +1188,48 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 	*done = false;
 	PartPlan pl;
 	uint64_t total_tiles = 0;
+	uint8_t* extra = nullptr;
 	bool ok = false;
-	int rc = part_prepare(f, base, 0, pl, &total_tiles, &ok);
+	int rc = part_prepare(f, base, 0, pl, &total_tiles, &extra, &ok);
 	if (rc || !ok)
 		return rc;
+	PartSide sd;
+	memset(&sd, 0, sizeof sd);
 	for (uint64_t t0 = 0; t0 < total_tiles; t0 += pl.tiles_per_batch) {
 		SeqArgs a = base;
 		a.first_tile = t0;
 		a.n_tiles = std::min<uint64_t>(pl.tiles_per_batch, total_tiles - t0);
 		{
 			ProfSpan ps(f, BTLBF_PROF_INSERT_HASH, s);
-			HIP_TRY(launch_part_hash(a, pl.pa, s)); // every writer publishes all of its region counts
+			HIP_TRY(launch_part_hash(a, pl.lv[0].out(), pl.lv[0].shift, sd, 0, s));
 		}
-		if (pl.pa.levels == 2) {
-			ProfSpan ps(f, BTLBF_PROF_INSERT_SPLIT, s);
-			HIP_TRY(launch_part_split(f->d_data, pl.pa, s));
-		}
-		{
-			ProfSpan ps(f, BTLBF_PROF_INSERT_APPLY, s);
-			HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, 0, s));
-		}
+		if ((rc = run_levels(f, pl, pl.lv[0].in(), sd, 0, s)))
+			return rc;
 	}
 	*done = true;
 	return BTLBF_OK;
 }
 
-// Partitioned contains() (DESIGN.md section 4.4): positions are partitioned exactly as for insert and
+// hit_bits := hit_bits with the windows owning a failed position cleared, for seq tiles
+// [first, first+n) of the direct kernels' tiling
+int resolve_range(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, const uint64_t* fail_list, uint64_t n_fail,
+                  uint64_t* table, uint64_t first, uint64_t n, hipStream_t s)
+{
+	SeqArgs d = base;
+	d.first_tile = first;
+	d.n_tiles = n;
+	d.hit_bits = hit_bits;
+	d.valid_bits = nullptr;
+	d.counts = nullptr;
+	HIP_TRY(hipMemsetAsync(table, 0, kFailTableSlots * 8, s));
+	HIP_TRY(launch_failset_build(fail_list, n_fail, table, kFailTableSlots - 1, s));
+	d.buckets = table;
+	d.bucket_cap = kFailTableSlots - 1;
+	HIP_TRY(launch_seq_op(OP_BF_RESOLVE, d, s));
+	return BTLBF_OK;
+}
+
+// Partitioned contains() (DESIGN.md section 4.3): positions are partitioned exactly as for insert and
 // TESTED against each segment in LDS; positions found clear go to a (small) fail list.  A batch
 // without failures is finished: every clean window hits.  Otherwise the failed positions become a
 // cache-resident hash set and one more hashing pass clears the windows that own one of them.  Too
@@ -1139,11 +1241,17 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	*done = false;
 	PartPlan pl;
 	uint64_t total_tiles = 0;
+	uint8_t* extra = nullptr;
 	bool ok = false;
-	int rc = part_prepare(f, base, kFailBytes, pl, &total_tiles, &ok);
+	int rc = part_prepare(f, base, kFailBytes, pl, &total_tiles, &extra, &ok);
 	if (rc || !ok)
 		return rc;
-	uint64_t* table = pl.pa.fail_list + kFailCap;
+	PartSide sd;
+	memset(&sd, 0, sizeof sd);
+	sd.fail_count = reinterpret_cast<unsigned long long*>(extra);
+	sd.fail_list = reinterpret_cast<uint64_t*>(extra + 256);
+	sd.fail_cap = kFailCap;
+	uint64_t* table = sd.fail_list + kFailCap;
 	if (counts)
 		HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
 	const uint64_t seq_tiles_all = (base.len + seq_tile_windows() - 1) / seq_tile_windows();
@@ -1155,40 +1263,32 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 		a.hit_bits = hit_bits;
 		a.valid_bits = valid_bits;
 		a.counts = counts; // pass A adds the clean-window count to counts[0]
-		HIP_TRY(hipMemsetAsync(pl.pa.fail_count, 0, 8, s));
+		HIP_TRY(hipMemsetAsync(sd.fail_count, 0, 8, s));
 		{
 			ProfSpan ps(f, BTLBF_PROF_QUERY_HASH, s);
-			HIP_TRY(launch_part_hash(a, pl.pa, s));
+			HIP_TRY(launch_part_hash(a, pl.lv[0].out(), pl.lv[0].shift, sd, 1, s));
 		}
-		if (pl.pa.levels == 2) {
-			ProfSpan ps(f, BTLBF_PROF_QUERY_SPLIT, s);
-			HIP_TRY(launch_part_split(f->d_data, pl.pa, s));
-		}
-		{
-			ProfSpan ps(f, BTLBF_PROF_QUERY_TEST, s);
-			HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.pa, 1, s));
-		}
+		if ((rc = run_levels(f, pl, pl.lv[0].in(), sd, 1, s)))
+			return rc;
 		unsigned long long n_fail = 0;
-		HIP_TRY(hipMemcpyAsync(&n_fail, pl.pa.fail_count, 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(&n_fail, sd.fail_count, 8, hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		if (n_fail == 0)
 			continue;
 		// redo / refine this batch's window range with the direct kernels (their tiles are smaller)
-		SeqArgs d = base;
-		d.first_tile = t0 * ratio;
-		d.n_tiles = std::min<uint64_t>(a.n_tiles * ratio, seq_tiles_all - d.first_tile);
-		d.hit_bits = hit_bits;
-		d.valid_bits = nullptr;
-		d.counts = nullptr;
+		const uint64_t first = t0 * ratio;
+		const uint64_t n = std::min<uint64_t>(a.n_tiles * ratio, seq_tiles_all - first);
 		ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
 		if (n_fail > kFailCap) {
+			SeqArgs d = base;
+			d.first_tile = first;
+			d.n_tiles = n;
+			d.hit_bits = hit_bits;
+			d.valid_bits = nullptr;
+			d.counts = nullptr;
 			HIP_TRY(launch_seq_op(OP_BF_CONTAINS, d, s));
-		} else {
-			HIP_TRY(hipMemsetAsync(table, 0, kFailTableSlots * 8, s));
-			HIP_TRY(launch_failset_build(pl.pa.fail_list, n_fail, table, kFailTableSlots - 1, s));
-			d.buckets = table;
-			d.bucket_cap = kFailTableSlots - 1;
-			HIP_TRY(launch_seq_op(OP_BF_RESOLVE, d, s));
+		} else if ((rc = resolve_range(f, base, hit_bits, sd.fail_list, n_fail, table, first, n, s))) {
+			return rc;
 		}
 	}
 	if (counts) // hits = set bits of the final bitmap
@@ -1237,6 +1337,204 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 	return BTLBF_OK;
 }
 
+// ---- multi-GPU routing (SURVEY.md 8e on the partitioned pipeline) -------------------------------------
+// The GLOBAL filter (size = f->mod.size, a power of two) is cut into 1024 level-0 bins; with W shards
+// owner g holds bins [g*1024/W, (g+1)*1024/W).  An origin partitions its probes into those bins (pass
+// A, regions = its CU count); the block of one owner is contiguous, so the exchange is a fixed-size
+// all-to-all of [1024/W bins][regions][cap][32] uint32 plus the entry counts.
+struct RoutePlan {
+	uint32_t shift0 = 0; // log2(positions per level-0 bin)
+	uint32_t bins_per_shard = 0;
+	uint32_t regions = 0;
+	uint32_t cap = 0;
+	uint64_t ent_bytes_per_shard = 0, cnt_bytes_per_shard = 0;
+};
+
+int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, unsigned n_shards, RoutePlan& rp)
+{
+	const uint64_t M = f->mod.size;
+	if (f->kind != BTLBF_BLOOM || !f->mod.pow2 || n_shards == 0 || (n_shards & (n_shards - 1)) || n_shards > 1024)
+		return fail(BTLBF_EINVAL, "routing needs a bit filter whose global size and shard count are powers of two");
+	if (!part_supported_h(f->hp.h) || !part_hash_fits(f->hp, 1024))
+		return fail(BTLBF_EINVAL, "routing does not support this hash configuration");
+	const unsigned lm = ceil_log2(M);
+	if (lm < 10 + 19 || lm - 10 > 32)
+		return fail(BTLBF_EINVAL, "routing supports global filters of 2^29 .. 2^42 bits");
+	rp.shift0 = lm - 10;
+	rp.bins_per_shard = 1024 / n_shards;
+	rp.regions = cu_count(f->device);
+	const uint64_t tile_w = (uint64_t)part_tile_windows();
+	const double entries = (double)((len + tile_w - 1) / tile_w) * probes_per_tile(f, lay);
+	rp.cap = chunks_for(entries / (1024.0 * rp.regions), 1);
+	rp.ent_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * rp.cap * 128;
+	rp.cnt_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * 4;
+	return BTLBF_OK;
+}
+
+} // namespace
+
+extern "C" int btlbf_route_plan(btlbf_filter* f, uint64_t len, const btlbf_layout* layout, unsigned n_shards,
+                                uint64_t* ent_bytes_per_shard, uint64_t* cnt_bytes_per_shard)
+{
+	if (!f || !ent_bytes_per_shard || !cnt_bytes_per_shard)
+		return fail(BTLBF_EINVAL, "null argument");
+	LayoutParams lay{nullptr, 0, 0};
+	if (layout) {
+		lay.starts = layout->starts;
+		lay.n_seqs = layout->n_seqs;
+		lay.read_len = layout->starts ? 0 : layout->read_len;
+	}
+	RoutePlan rp;
+	int rc = route_plan(f, len, lay, n_shards, rp);
+	if (rc)
+		return rc;
+	*ent_bytes_per_shard = rp.ent_bytes_per_shard;
+	*cnt_bytes_per_shard = rp.cnt_bytes_per_shard;
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
+                                uint64_t plan_len, unsigned n_shards, int query, void* send_ent, void* send_cnt,
+                                uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts, uint64_t* spill_list,
+                                uint64_t spill_cap, uint64_t* spill_count, void* stream)
+{
+	int rc = seq_precheck(f, len);
+	if (rc)
+		return rc;
+	if (!send_ent || !send_cnt || !spill_list || !spill_count)
+		return fail(BTLBF_EINVAL, "null argument");
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	SeqView v;
+	if ((rc = make_view(v, seq, len, layout, BTLBF_DEVICE, s)))
+		return rc;
+	RoutePlan rp;
+	if ((rc = route_plan(f, plan_len, v.lay, n_shards, rp)))
+		return rc;
+	SeqArgs a = base_args(f, v, len);
+	fill_mod(a.mod, f->mod.size, 0, f->mod.size); // positions of the GLOBAL filter
+	a.hit_bits = reinterpret_cast<uint8_t*>(hit_bits);
+	a.valid_bits = reinterpret_cast<uint8_t*>(valid_bits);
+	a.counts = counts;
+	const uint64_t tile_w = (uint64_t)part_tile_windows();
+	a.first_tile = 0;
+	a.n_tiles = (len + tile_w - 1) / tile_w;
+	PartOut out{1024, rp.regions, rp.cap, static_cast<uint32_t*>(send_cnt), static_cast<uint32_t*>(send_ent)};
+	PartSide sd;
+	memset(&sd, 0, sizeof sd);
+	sd.spill_list = spill_list;
+	sd.spill_count = reinterpret_cast<unsigned long long*>(spill_count);
+	sd.spill_cap = spill_cap;
+	HIP_TRY(hipMemsetAsync(spill_count, 0, 8, s));
+	if (counts)
+		HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
+	if (a.n_tiles == 0) { // nothing to hash: still publish empty regions
+		HIP_TRY(hipMemsetAsync(send_cnt, 0, (size_t)rp.cnt_bytes_per_shard * n_shards, s));
+		return BTLBF_OK;
+	}
+	ProfSpan ps(f, query ? BTLBF_PROF_QUERY_HASH : BTLBF_PROF_INSERT_HASH, s);
+	HIP_TRY(launch_part_hash(a, out, rp.shift0, sd, query, s));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
+                                  uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards, int query,
+                                  uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream)
+{
+	if (!f || !recv_ent || !recv_cnt || n_blocks == 0)
+		return fail(BTLBF_EINVAL, "null argument");
+	if (f->shard_count != n_shards)
+		return fail(BTLBF_EINVAL, "filter is shard %u of %u, not of %u", f->shard_index, f->shard_count, n_shards);
+	if (query && (!fail_list || !fail_count))
+		return fail(BTLBF_EINVAL, "query needs a fail list");
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	LayoutParams lay{nullptr, 0, 0};
+	if (layout) {
+		lay.n_seqs = layout->n_seqs;
+		lay.read_len = layout->starts ? 0 : layout->read_len;
+		lay.starts = layout->starts;
+	}
+	RoutePlan rp;
+	int rc = route_plan(f, plan_len, lay, n_shards, rp);
+	if (rc)
+		return rc;
+	PartPlan pl;
+	if (!plan_segments(f->mod.shard_len, pl))
+		return fail(BTLBF_EINVAL, "shard too large for the partitioned pipeline");
+	pl.lv[0].bins = rp.bins_per_shard;
+	pl.lv[0].shift = rp.shift0;
+	pl.lv[0].regions = rp.regions * n_blocks;
+	if (pl.lv[0].shift < pl.seg_shift || !plan_splits(pl, pl.lv[0].regions))
+		return fail(BTLBF_EINVAL, "unsupported shard geometry");
+	// every origin sends about entries/n_shards to this shard; n_blocks origins
+	const uint64_t tile_w = (uint64_t)part_tile_windows();
+	const double entries = (double)((plan_len + tile_w - 1) / tile_w) * probes_per_tile(f, lay) * n_blocks / n_shards;
+	plan_caps(pl, entries, 1);
+	bool ok = false;
+	if ((rc = ensure_scratch(f, pl.bytes_total, &ok)))
+		return rc;
+	if (!ok)
+		return fail(BTLBF_ENOMEM, "no room for %llu bytes of partition scratch", (unsigned long long)pl.bytes_total);
+	carve_levels(pl, static_cast<uint8_t*>(f->d_part), 1);
+	PartSide sd;
+	memset(&sd, 0, sizeof sd);
+	sd.pos_base = f->mod.shard_lo;
+	sd.fail_list = fail_list;
+	sd.fail_count = reinterpret_cast<unsigned long long*>(fail_count);
+	sd.fail_cap = fail_cap;
+	PartIn in0{n_blocks, rp.bins_per_shard, rp.regions, rp.cap, static_cast<const uint32_t*>(recv_cnt),
+	           static_cast<const uint32_t*>(recv_ent)};
+	return run_levels(f, pl, in0, sd, query, s);
+}
+
+extern "C" int btlbf_apply_spill(btlbf_filter* f, const uint64_t* global_pos, uint64_t n, int query,
+                                 uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream)
+{
+	if (!f || (n && !global_pos))
+		return fail(BTLBF_EINVAL, "null argument");
+	if (f->kind != BTLBF_BLOOM)
+		return fail(BTLBF_EINVAL, "bit filters only");
+	DeviceGuard g(f->device);
+	PartSide sd;
+	memset(&sd, 0, sizeof sd);
+	sd.fail_list = fail_list;
+	sd.fail_count = reinterpret_cast<unsigned long long*>(fail_count);
+	sd.fail_cap = fail_cap;
+	HIP_TRY(launch_spill(f->d_data, global_pos, n, f->mod.shard_lo, f->mod.shard_len, query, sd,
+	                     static_cast<hipStream_t>(stream)));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_resolve_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
+                                  const uint64_t* fail_list, uint64_t n_fail, uint64_t* hit_bits, void* stream)
+{
+	int rc = seq_precheck(f, len);
+	if (rc)
+		return rc;
+	if (!hit_bits || (n_fail && !fail_list))
+		return fail(BTLBF_EINVAL, "null argument");
+	if (n_fail == 0 || len == 0)
+		return BTLBF_OK;
+	if (n_fail > kFailCap)
+		return fail(BTLBF_EINVAL, "more than %llu failed positions: use the direct query", (unsigned long long)kFailCap);
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	SeqView v;
+	if ((rc = make_view(v, seq, len, layout, BTLBF_DEVICE, s)))
+		return rc;
+	bool ok = false;
+	if ((rc = ensure_scratch(f, kFailTableSlots * 8, &ok)))
+		return rc;
+	if (!ok)
+		return fail(BTLBF_ENOMEM, "no room for the failed-position set");
+	SeqArgs a = base_args(f, v, len);
+	fill_mod(a.mod, f->mod.size, 0, f->mod.size); // global positions
+	return resolve_range(f, a, reinterpret_cast<uint8_t*>(hit_bits), fail_list, n_fail,
+	                     static_cast<uint64_t*>(f->d_part), 0, 0, s);
+}
+
+namespace {
 } // namespace
 
 extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,

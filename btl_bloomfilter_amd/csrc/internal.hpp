@@ -117,26 +117,37 @@ struct SeqArgs {
 	uint64_t tiles_per_block;
 };
 
-// Geometry and scratch of the partitioned insert (partition_kernels.hip).  A SEGMENT is
-// 2^seg_shift bits of the local array (64 KiB or 128 KiB: what one workgroup holds in LDS).
-struct PartArgs {
-	uint32_t levels;    // 1: pass A bins are segments; 2: pass A bins hold p1 segments each
-	uint32_t seg_shift; // log2(bits per segment)
-	uint32_t bin_shift; // log2(bits per level-0 bin) = seg_shift + log2(p1)
-	uint32_t p0, p1;    // level-0 bins (<= 1024); sub-bins per level-0 bin (power of two <= 1024)
-	uint64_t n_seg;
-	// every bin is written by several workgroups, each into its own REGION of cap chunks:
-	// region index = bin * regions + writer
-	uint32_t regions0, regions1; // writers per level-0 bin (= pass-A workgroups) / per sub-bin
-	uint32_t cap0, cap1;         // region capacity in 32-entry chunks
-	uint32_t* cur0;              // [p0*regions0] chunks written per region
-	uint32_t* cur1;              // [p0*p1*regions1]
-	uint32_t* out0;              // [p0*regions0][cap0][32]
-	uint32_t* out1;              // [p0*p1*regions1][cap1][32]
-	// partitioned query: positions whose bit was found clear are appended here
-	uint64_t* fail_list;
+// ---- partitioned insert / contains (partition_kernels.hip) -------------------------------------------
+// A SEGMENT is 2^seg_shift bits of the local array (64 KiB or 128 KiB: what one workgroup holds in
+// LDS).  A partition pass writes BINS; every bin is written by several workgroups, each into its own
+// REGION of `cap` 32-entry chunks: region index = bin * regions + writer.
+struct PartOut {
+	uint32_t P;       // bins one workgroup writes (its output block)
+	uint32_t regions; // writers per bin
+	uint32_t cap;     // region capacity in chunks
+	uint32_t* cnt;    // [bins * regions] ENTRIES per region
+	uint32_t* ent;    // [bins * regions][cap][32]
+};
+// How a pass reads the regions of its input bins.  Data that arrived through the multi-GPU exchange
+// consists of `blocks` origin blocks, each laid out [bins_per_block][regions_per_block][cap][32];
+// region r of bin b is ((r / regions_per_block) * bins_per_block + b) * regions_per_block + r % regions_per_block.
+struct PartIn {
+	uint32_t blocks;
+	uint32_t bins_per_block;
+	uint32_t regions_per_block;
+	uint32_t cap;
+	const uint32_t* cnt;
+	const uint32_t* ent;
+};
+// side channels of a pass
+struct PartSide {
+	uint64_t pos_base;              // added to local positions that are reported (fail / spill lists)
+	uint64_t* fail_list;            // partitioned contains: positions whose bit was found clear
 	unsigned long long* fail_count;
 	uint64_t fail_cap;
+	uint64_t* spill_list;           // routing (multi-GPU): entries that could not be staged, as global positions
+	unsigned long long* spill_count; // nullptr = overflow goes straight to this GPU's array
+	uint64_t spill_cap;
 };
 
 // launchers (defined in the .hip files)
@@ -144,10 +155,15 @@ int part_tile_windows();
 bool part_supported_h(uint32_t h);
 uint32_t part_hash_lds_bytes(const HashParams& hp, uint32_t p0);
 bool part_hash_fits(const HashParams& hp, uint32_t p0);
-hipError_t launch_part_hash(const SeqArgs& a, const PartArgs& pa, hipStream_t s);
-hipError_t launch_part_split(void* filter, const PartArgs& pa, hipStream_t s);
-hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs& pa, int test_only, hipStream_t s);
+hipError_t launch_part_hash(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd, int query,
+                            hipStream_t s);
+hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t n_in_bins, const PartOut& out,
+                             uint32_t sub_shift, uint32_t in_shift, const PartSide& sd, int query, hipStream_t s);
+hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_shift, uint64_t n_seg, const PartIn& in,
+                             const PartSide& sd, int query, hipStream_t s);
 hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t* table, uint64_t mask, hipStream_t s);
+hipError_t launch_spill(void* filter, const uint64_t* pos, uint64_t n, uint64_t lo, uint64_t len, int test,
+                        const PartSide& sd, hipStream_t s);
 hipError_t launch_seq_op(int op, const SeqArgs& a, hipStream_t s);
 hipError_t launch_hash_op(int op, void* filter, const ModParams& mod, uint32_t h, uint32_t threshold,
                           const uint64_t* hashes, uint64_t n, uint8_t* out, int serial, hipStream_t s);

@@ -1,25 +1,27 @@
-// csrc/partition_kernels.hip -- partitioned insert: turn h random HBM atomics per k-mer into streamed
-// traffic plus LDS atomics.
+// csrc/partition_kernels.hip -- partitioned insert / contains: turn h random HBM requests per k-mer
+// into streamed traffic plus LDS atomics.
 //
-// Why: the direct insert kernel is pinned to the memory system's random-request rate (~22 G
-// memory-side atomics/s on MI355X).  Bit OR is order-free, so a batch of probe
-// positions may be applied in any order -- in particular grouped by the 64 KiB (or 128 KiB) filter
-// SEGMENT they fall into, with that segment held in LDS.  The result is bit-identical.
+// Why: the direct kernels are pinned to the memory system's random-request rate (~22 G memory-side
+// atomics/s, ~50 G gathers/s on MI355X).  Bit OR is order-free, so a batch of
+// probe positions may be applied in any order -- in particular grouped by the 64 KiB (or 128 KiB)
+// filter SEGMENT they fall into, with that segment held in LDS.  The result is bit-identical.
 //
-//   pass A  part_hash_kernel   fused ntHash (seq_core.hpp) + radix partition of the local positions
-//                              by their top bits into p0 <= 1024 level-0 bins
-//   pass B  part_split_kernel  (filters with more than 1024 segments) splits every level-0 bin into
-//                              p1 <= 1024 sub-bins = segments
-//   pass C  part_apply_kernel  one workgroup per segment: load the segment into LDS, ds_or every
-//                              entry, store the segment back
+//   pass A  part_hash_kernel   fused ntHash (seq_core.hpp) + radix partition of the positions by
+//                              their top bits into <= 1024 level-0 bins
+//   pass B  part_split_kernel  splits every bin of one level into <= 1024 sub-bins (run once, or
+//                              twice when the data arrives pre-binned from other GPUs)
+//   pass C  part_apply_kernel  one workgroup per segment: load the segment into LDS, ds_or (insert)
+//                              or test (contains) every entry, store the segment back (insert)
 //
-// Bins are written as 128-byte CHUNKS (32 uint32 entries).  A workgroup stages entries per bin in an
-// LDS ring and writes a chunk only when it is full, so every global write is one aligned 128-byte
-// line.  Every workgroup writes into its OWN region of every bin (region = (bin, writer)), so chunk
-// slots are handed out from an LDS counter: no global atomics anywhere in passes A and B.  Chunks
-// flushed at kernel end are padded with a sentinel.  Entries that do not fit (a region over capacity,
-// or a bin that receives more than about two rings' worth inside one round) are applied to the
-// filter directly with atomicOr -- never dropped.
+// Bins are written as 128-byte CHUNKS (32 uint32 entries; an entry is the position's offset inside
+// its bin).  A workgroup stages entries per bin in an LDS ring and writes a chunk only when it is
+// full, so every global write is one aligned 128-byte line.  Every workgroup writes into its OWN
+// region of every bin (region = (bin, writer)), so chunk slots are handed out from an LDS counter:
+// no global atomics in passes A and B.  The number of ENTRIES of each region is published at kernel
+// end (the tail chunk is partial).  Entries that do not fit (a region over capacity, or a bin that
+// receives more than about two rings' worth inside one round) take the overflow path: applied to
+// the filter directly (single GPU) or appended to a spill list of global positions (multi-GPU
+// routing) -- never dropped.
 #include "seq_core.hpp"
 
 namespace btlbf {
@@ -30,9 +32,9 @@ static constexpr int kPartThreads = 1024;
 static constexpr int kPartW = 4;                        // windows per lane in pass A
 static constexpr int kPartTile = kPartThreads * kPartW; // windows per round of pass A
 static constexpr int kApplyThreads = 512;
-static constexpr uint32_t kChunk = 32;              // entries per chunk
-static constexpr uint32_t kSentinel = 0xffffffffu;
-static constexpr uint32_t kStageEntries = 32768;    // LDS staging: 128 KiB of uint32 entries
+static constexpr uint32_t kChunk = 32;           // entries per chunk
+static constexpr uint32_t kNoBin = 0xffffffffu;  // empty entry slot of a lane (registers only)
+static constexpr uint32_t kStageEntries = 32768; // LDS staging: 128 KiB of uint32 entries
 static constexpr uint32_t kPartLdsBudget = 160 * 1024 - 1024; // dynamic LDS a workgroup may ask for
 
 // LDS image of the staged partitioner (carved from dynamic LDS by the kernels)
@@ -42,7 +44,7 @@ struct PartLds {
 	uint32_t* hist;    // [P] entries offered to the bin this round
 	uint32_t* fl;      // [P] entries flushed from the bin this round (multiple of 32)
 	uint32_t* written; // [P] chunks written to this workgroup's region of the bin
-	uint32_t* fout;    // [1024] output chunk index (inside `out`) of each flush item
+	uint32_t* fout;    // [1024] output chunk index (inside the pass's output array) of each flush item
 	uint16_t* flist;   // [1024] flush items: bin | ring chunk << 10
 	uint32_t* fcount;
 	uint32_t sc_shift; // log2(SC)
@@ -92,26 +94,21 @@ __device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
 		*l.fcount = 0;
 }
 
-// One round: every thread contributes E entries (bin[e] == kSentinel marks an empty slot).
-// Precondition: hist[] all zero, fcount zero, and a barrier since they were written.
-// Region r of bin b is chunks [(b*n_regions + r)*cap_chunks, +cap_chunks) of `out` (32-bit chunk
-// indices: the scratch holds fewer than 2^32 chunks).  `ovf(bin, val)` must apply the entry to the
-// filter directly.
 #ifdef BTLBF_PHASE_STAMPS
-#define STAMP(i)                                             \
-	do {                                                     \
-		if (threadIdx.x == 0) {                              \
+#define STAMP(i)                                               \
+	do {                                                       \
+		if (threadIdx.x == 0) {                                \
 			const uint64_t t__ = __builtin_readcyclecounter(); \
-			g_stamp[i] += t__ - g_last;                      \
-			g_last = t__;                                    \
-		}                                                    \
+			g_stamp[i] += t__ - g_last;                        \
+			g_last = t__;                                      \
+		}                                                      \
 	} while (0)
 static __device__ uint64_t g_stamp_out[16];
 #define STAMP_DECL uint64_t g_stamp[16] = {0}, g_last = __builtin_readcyclecounter()
-#define STAMP_FLUSH                                                      \
-	do {                                                                 \
-		if (threadIdx.x == 0)                                            \
-			for (int i__ = 0; i__ < 16; ++i__)                           \
+#define STAMP_FLUSH                                                                                  \
+	do {                                                                                             \
+		if (threadIdx.x == 0)                                                                        \
+			for (int i__ = 0; i__ < 16; ++i__)                                                       \
 				atomicAdd((unsigned long long*)&g_stamp_out[i__], (unsigned long long)g_stamp[i__]); \
 	} while (0)
 #define STAMP_ARGS , uint64_t (&g_stamp)[16], uint64_t& g_last
@@ -124,25 +121,31 @@ static __device__ uint64_t g_stamp_out[16];
 #define STAMP_PASS
 #endif
 
+// One round: every thread contributes E entries (bin[e] == kNoBin marks an empty slot) to the bins
+// [0, o.P) of this workgroup's output block; block-local bin b is global bin bin0 + b.
+// Precondition: hist[] all zero, fcount zero, and a barrier since they were written.
+// Region `region` of global bin g is chunks [(g*o.regions + region)*o.cap, +o.cap) of o.ent
+// (32-bit chunk indices: a pass's output holds fewer than 2^32 chunks).
+// `ovf(bin, val)` takes the entries that cannot be staged.
 template <int NT, int E, class OVF>
-__device__ __forceinline__ void part_round(const PartLds& l, uint32_t P, const uint32_t (&bin)[E],
-                                           const uint32_t (&val)[E], uint32_t* out, uint32_t n_regions,
-                                           uint32_t region, uint32_t cap_chunks, OVF&& ovf STAMP_ARGS)
+__device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
+                                           const uint32_t (&bin)[E], const uint32_t (&val)[E], OVF&& ovf STAMP_ARGS)
 {
 	const uint32_t tid = threadIdx.x;
+	const uint32_t P = o.P;
 	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
 	uint32_t rank[E];
 	uint32_t staged = 0; // bit e: entry e found room in the ring before this round's flush
 	static_assert(E <= 32, "one flag bit per entry");
 #pragma unroll
 	for (int e = 0; e < E; ++e)
-		rank[e] = bin[e] != kSentinel ? atomicAdd(&l.hist[bin[e]], 1u) : 0;
+		rank[e] = bin[e] != kNoBin ? atomicAdd(&l.hist[bin[e]], 1u) : 0;
 	__syncthreads();
 	STAMP(3);
 	// entries that fit behind what the ring already holds are staged now
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
-		if (bin[e] != kSentinel) {
+		if (bin[e] != kNoBin) {
 			const uint32_t w = l.pt[bin[e]];
 			if ((w >> 16) + rank[e] < SC) {
 				l.stage[(bin[e] << l.sc_shift) + ((w + rank[e]) & ring)] = val[e];
@@ -163,10 +166,10 @@ __device__ __forceinline__ void part_round(const PartLds& l, uint32_t P, const u
 			const uint32_t base = atomicAdd(l.fcount, nfl);
 			const uint32_t w0 = l.written[b];
 			const uint32_t hc = ((w - occ) & ring) >> 5; // ring chunk at the read position
-			const uint32_t o0 = (b * n_regions + region) * cap_chunks;
+			const uint32_t o0 = ((bin0 + b) * o.regions + region) * o.cap;
 			for (uint32_t c = 0; c < nfl; ++c) {
 				l.flist[base + c] = (uint16_t)(b | (((hc + c) & (ring >> 5)) << 10));
-				l.fout[base + c] = w0 + c < cap_chunks ? o0 + w0 + c : 0xffffffffu;
+				l.fout[base + c] = w0 + c < o.cap ? o0 + w0 + c : 0xffffffffu;
 			}
 			l.written[b] = w0 + nfl;
 		}
@@ -182,7 +185,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, uint32_t P, const u
 			const uint32_t b = it & 1023, rc = it >> 10;
 			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(b << l.sc_shift) + (rc << 5) + l8 * 4]);
 			if (oc != 0xffffffffu) {
-				*reinterpret_cast<uint4*>(&out[(uint64_t)oc * kChunk + l8 * 4]) = v;
+				*reinterpret_cast<uint4*>(&o.ent[(uint64_t)oc * kChunk + l8 * 4]) = v;
 			} else {
 				ovf(b, v.x);
 				ovf(b, v.y);
@@ -193,25 +196,23 @@ __device__ __forceinline__ void part_round(const PartLds& l, uint32_t P, const u
 	}
 	__syncthreads();
 	STAMP(6);
-	// entries that did not fit before the flush: into the freed ring space, else applied directly
-	{
+	// entries that did not fit before the flush: into the freed ring space, else overflow
 #pragma unroll
-		for (int e = 0; e < E; ++e) {
-			if (bin[e] != kSentinel && !((staged >> e) & 1)) {
-				const uint32_t w = l.pt[bin[e]];
-				if ((w >> 16) + rank[e] - l.fl[bin[e]] < SC)
-					l.stage[(bin[e] << l.sc_shift) + ((w + rank[e]) & ring)] = val[e];
-				else
-					ovf(bin[e], val[e]);
-			}
+	for (int e = 0; e < E; ++e) {
+		if (bin[e] != kNoBin && !((staged >> e) & 1)) {
+			const uint32_t w = l.pt[bin[e]];
+			if ((w >> 16) + rank[e] - l.fl[bin[e]] < SC)
+				l.stage[(bin[e] << l.sc_shift) + ((w + rank[e]) & ring)] = val[e];
+			else
+				ovf(bin[e], val[e]);
 		}
 	}
 	__syncthreads();
 	STAMP(7);
 	for (uint32_t b = tid; b < P; b += NT) {
 		const uint32_t w = l.pt[b], occ = w >> 16, f = l.fl[b];
-		const uint32_t tot = occ + l.hist[b] - f; // wants to be in the ring after the flush
-		const uint32_t nocc = tot < SC ? tot : SC; // entries beyond went to the filter directly
+		const uint32_t tot = occ + l.hist[b] - f;  // wants to be in the ring after the flush
+		const uint32_t nocc = tot < SC ? tot : SC; // entries beyond took the overflow path
 		const uint32_t accepted = nocc + f - occ;
 		l.pt[b] = ((w + accepted) & 0xffffu) | (nocc << 16);
 		l.hist[b] = 0;
@@ -222,45 +223,68 @@ __device__ __forceinline__ void part_round(const PartLds& l, uint32_t P, const u
 	// the caller's next barrier orders these writes before the next round
 }
 
-// flush whatever is staged (padded with the sentinel) and publish the chunk counts of this region
+// flush whatever is staged and publish the ENTRY count of this workgroup's region of every bin
 template <int NT, class OVF>
-__device__ __forceinline__ void part_finish(const PartLds& l, uint32_t P, uint32_t* out, uint32_t* counts,
-                                            uint32_t n_regions, uint32_t region, uint32_t cap_chunks, OVF&& ovf)
+__device__ __forceinline__ void part_finish(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
+                                            OVF&& ovf)
 {
 	__syncthreads();
 	const uint32_t tid = threadIdx.x, lane32 = tid & 31;
 	const uint32_t ring = (1u << l.sc_shift) - 1;
-	for (uint32_t b = tid >> 5; b < P; b += NT / 32) {
+	for (uint32_t b = tid >> 5; b < o.P; b += NT / 32) {
 		const uint32_t w = l.pt[b], n = w >> 16, hd = (w - n) & ring;
-		uint32_t oc = l.written[b];
-		const uint32_t o0 = (b * n_regions + region) * cap_chunks;
-		for (uint32_t c = 0; c * kChunk < n; ++c, ++oc) {
+		const uint32_t w0 = l.written[b];
+		const uint32_t full = w0 < o.cap ? w0 : o.cap; // chunks of this region that really hold data
+		const uint32_t o0 = ((bin0 + b) * o.regions + region) * o.cap;
+		uint32_t stored = 0;
+		for (uint32_t c = 0; c * kChunk < n; ++c) {
 			const uint32_t i = c * kChunk + lane32;
-			const uint32_t v = i < n ? l.stage[(b << l.sc_shift) + ((hd + i) & ring)] : kSentinel;
-			if (oc < cap_chunks)
-				out[(uint64_t)(o0 + oc) * kChunk + lane32] = v;
-			else if (v != kSentinel)
+			const uint32_t v = i < n ? l.stage[(b << l.sc_shift) + ((hd + i) & ring)] : 0;
+			if (w0 + c < o.cap) {
+				o.ent[(uint64_t)(o0 + w0 + c) * kChunk + lane32] = v;
+				stored = (c + 1) * kChunk < n ? (c + 1) * kChunk : n;
+			} else if (i < n) {
 				ovf(b, v);
+			}
 		}
 		if (lane32 == 0)
-			counts[b * n_regions + region] = oc < cap_chunks ? oc : cap_chunks;
+			o.cnt[(bin0 + b) * o.regions + region] = full * kChunk + stored;
 	}
 }
 
-// ---- pass A --------------------------------------------------------------------------------------
-// bin = local_position >> bin_shift ; entry = local_position & ((1 << bin_shift) - 1)
-// region = blockIdx.x (gridDim.x == pa.regions0)
-// QUERY = true: positions are partitioned for testing, not setting; an entry that cannot be staged
-// is tested against the filter right away and reported through the fail list if its bit is clear
-__device__ __forceinline__ void part_report_fail(const PartArgs& pa, uint64_t local_pos)
+// where the overflow entries of the routing passes go (multi-GPU): global positions
+__device__ __forceinline__ void part_spill(const PartSide& sd, uint64_t pos)
 {
-	const unsigned long long i = atomicAdd(pa.fail_count, 1ull);
-	if (i < pa.fail_cap)
-		pa.fail_list[i] = local_pos;
+	const unsigned long long i = atomicAdd(sd.spill_count, 1ull);
+	if (i < sd.spill_cap)
+		sd.spill_list[i] = pos;
+}
+// positions whose bit was found clear (partitioned contains)
+__device__ __forceinline__ void part_report_fail(const PartSide& sd, uint64_t pos)
+{
+	const unsigned long long i = atomicAdd(sd.fail_count, 1ull);
+	if (i < sd.fail_cap)
+		sd.fail_list[i] = pos;
+}
+// overflow of an insert / contains pass: spill list when routing, else straight to the filter
+template <bool QUERY>
+__device__ __forceinline__ void part_direct(uint32_t* words, const PartSide& sd, uint64_t lp)
+{
+	if (sd.spill_count)
+		part_spill(sd, sd.pos_base + lp);
+	else if (!QUERY)
+		bf_set(words, lp);
+	else if (!((bf_word(words, lp) >> (lp & 31)) & 1u))
+		part_report_fail(sd, sd.pos_base + lp);
 }
 
+// ---- pass A --------------------------------------------------------------------------------------
+// bin = position >> bin_shift ; entry = position & ((1 << bin_shift) - 1); region = blockIdx.x
+// (gridDim.x == out.regions).  `position` is local to a.mod's shard window (the whole filter in
+// routing mode, where a.mod describes the GLOBAL filter).
 template <int H, bool POW2, bool SPACED, bool QUERY>
-__global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a, const PartArgs pa)
+__global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a, const PartOut out,
+                                                                const uint32_t bin_shift, const PartSide sd)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	__shared__ SeqShared sh;
@@ -269,20 +293,13 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 	const uint32_t tile_cap = seq_tile_cap(kPartTile, k);
 	uint8_t* tile = dyn;
 	uint8_t* spaced_lds = dyn + tile_cap;
-	const PartLds pl = part_carve(dyn + tile_cap + seq_spaced_bytes(a.hp), pa.p0);
+	const PartLds pl = part_carve(dyn + tile_cap + seq_spaced_bytes(a.hp), out.P);
 	seq_setup_tables<kPartThreads, SPACED>(sh, a.hp, spaced_lds);
-	part_init<kPartThreads>(pl, pa.p0);
+	part_init<kPartThreads>(pl, out.P);
 
 	uint32_t* words = static_cast<uint32_t*>(a.filter);
-	const uint32_t bin_shift = pa.bin_shift;
-	const uint32_t ent_mask = (uint32_t)((1ull << bin_shift) - 1);
-	auto ovf = [&](uint32_t b, uint32_t v) {
-		const uint64_t lp = ((uint64_t)b << bin_shift) | v;
-		if (!QUERY)
-			bf_set(words, lp);
-		else if (!((bf_word(words, lp) >> (lp & 31)) & 1u))
-			part_report_fail(pa, lp);
-	};
+	const uint32_t ent_mask = bin_shift >= 32 ? 0xffffffffu : (1u << bin_shift) - 1;
+	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, ((uint64_t)b << bin_shift) | v); };
 	const bool sharded = a.mod.shard_len != a.mod.size;
 	const uint64_t out_bytes = ((a.len + 63) / 64) * 8;
 	uint32_t my_valid = 0;
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 					p -= a.mod.shard_lo;
 					mine = ok && p < a.mod.shard_len;
 				}
-				bin[w * H + i] = mine ? (uint32_t)(p >> bin_shift) : kSentinel;
+				bin[w * H + i] = mine ? (uint32_t)(p >> bin_shift) : kNoBin;
 				val[w * H + i] = (uint32_t)p & ent_mask;
 			}
 		});
@@ -336,9 +353,9 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 		}
 		my_valid += __popc(vmask);
 		STAMP(2);
-		part_round<kPartThreads, kPartW * H>(pl, pa.p0, bin, val, pa.out0, pa.regions0, blockIdx.x, pa.cap0, ovf STAMP_PASS);
+		part_round<kPartThreads, kPartW * H>(pl, out, 0, blockIdx.x, bin, val, ovf STAMP_PASS);
 	}
-	part_finish<kPartThreads>(pl, pa.p0, pa.out0, pa.cur0, pa.regions0, blockIdx.x, pa.cap0, ovf);
+	part_finish<kPartThreads>(pl, out, 0, blockIdx.x, ovf);
 	if (a.counts) {
 		const uint32_t wv = wave_sum(my_valid);
 		if ((tid & 63) == 0 && wv)
@@ -348,94 +365,98 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 	STAMP_FLUSH;
 }
 
+// region r of input bin b: the data may consist of several origin blocks (multi-GPU exchange)
+__device__ __forceinline__ uint32_t part_in_region(const PartIn& in, uint32_t b, uint32_t r)
+{
+	return ((r / in.regions_per_block) * in.bins_per_block + b) * in.regions_per_block + r % in.regions_per_block;
+}
+
 // ---- pass B --------------------------------------------------------------------------------------
-// workgroup (b0, g): blockIdx.x = b0 * regions1 + g.  It consumes pass-A regions g, g+regions1, ...
-// of level-0 bin b0 and writes region g of every sub-bin of b0.
-// entry e -> sub-bin e >> seg_shift, new entry e & seg_mask.
+// workgroup (b, g): blockIdx.x = b * slices + g.  It consumes input regions g, g+slices, ... of input
+// bin b and writes region g of every sub-bin b*P + sub, sub = entry >> sub_shift; the new entry is
+// the low sub_shift bits.  in_shift = log2(positions per input bin), for the overflow path.
 template <bool QUERY>
-__global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, const PartArgs pa)
+__global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, const PartIn in, const PartOut out,
+                                                                 const uint32_t slices, const uint32_t sub_shift,
+                                                                 const uint32_t in_shift, const PartSide sd)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	const uint32_t tid = threadIdx.x;
-	const uint32_t b0 = blockIdx.x / pa.regions1, g = blockIdx.x % pa.regions1;
-	const PartLds pl = part_carve(dyn, pa.p1);
-	part_init<kPartThreads>(pl, pa.p1);
+	const uint32_t b = blockIdx.x / slices, g = blockIdx.x % slices;
+	const PartLds pl = part_carve(dyn, out.P);
+	part_init<kPartThreads>(pl, out.P);
 	uint32_t* words = static_cast<uint32_t*>(filter);
-	const uint32_t seg_shift = pa.seg_shift;
-	const uint32_t seg_mask = (1u << seg_shift) - 1;
-	const uint64_t bin_base = (uint64_t)b0 << pa.bin_shift;
+	const uint32_t sub_mask = (1u << sub_shift) - 1;
+	const uint64_t bin_base = (uint64_t)b << in_shift;
 	auto ovf = [&](uint32_t sub, uint32_t v) {
-		const uint64_t lp = bin_base | ((uint64_t)sub << seg_shift) | v;
-		if (!QUERY)
-			bf_set(words, lp);
-		else if (!((bf_word(words, lp) >> (lp & 31)) & 1u))
-			part_report_fail(pa, lp);
+		part_direct<QUERY>(words, sd, bin_base | ((uint64_t)sub << sub_shift) | v);
 	};
-
-	uint32_t* cur = pa.cur1 + (uint64_t)b0 * pa.p1 * pa.regions1;
-	uint32_t* out = pa.out1 + (uint64_t)b0 * pa.p1 * pa.regions1 * pa.cap1 * kChunk;
+	const uint32_t bin0 = b * out.P;
+	const uint32_t n_regions_in = in.blocks * in.regions_per_block;
 	constexpr int kVec = 4; // uint4 loads per thread per round -> 16 entries
 	STAMP_DECL;
 	__syncthreads();
-	for (uint32_t r = g; r < pa.regions0; r += pa.regions1) {
-		const uint64_t reg = (uint64_t)b0 * pa.regions0 + r;
-		uint32_t n_chunks = pa.cur0[reg];
-		if (n_chunks > pa.cap0)
-			n_chunks = pa.cap0;
-		const uint4* src = reinterpret_cast<const uint4*>(pa.out0 + reg * pa.cap0 * kChunk);
-		const uint32_t n_vec = n_chunks * (kChunk / 4);
+	for (uint32_t r = g; r < n_regions_in; r += slices) {
+		const uint32_t reg = part_in_region(in, b, r);
+		uint32_t n = in.cnt[reg];
+		if (n > in.cap * kChunk)
+			n = in.cap * kChunk;
+		const uint4* src = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg * in.cap * kChunk);
+		const uint32_t n_vec = (n + 3) / 4;
 		// software pipeline: the next round's loads are in flight while this round is partitioned
 		uint4 nxt[kVec];
 #pragma unroll
 		for (int v = 0; v < kVec; ++v) {
 			const uint32_t i = (uint32_t)v * kPartThreads + tid;
-			nxt[v] = i < n_vec ? src[i] : make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
+			nxt[v] = i < n_vec ? src[i] : make_uint4(0, 0, 0, 0);
 		}
 		for (uint32_t base = 0; base < n_vec; base += kPartThreads * kVec) {
 			uint32_t bin[kVec * 4], val[kVec * 4];
 #pragma unroll
 			for (int v = 0; v < kVec; ++v) {
 				const uint32_t e4[4] = {nxt[v].x, nxt[v].y, nxt[v].z, nxt[v].w};
+				const uint32_t i0 = (base + (uint32_t)v * kPartThreads + tid) * 4;
 #pragma unroll
 				for (int c = 0; c < 4; ++c) {
-					bin[v * 4 + c] = e4[c] == kSentinel ? kSentinel : e4[c] >> seg_shift;
-					val[v * 4 + c] = e4[c] & seg_mask;
+					bin[v * 4 + c] = i0 + c < n ? e4[c] >> sub_shift : kNoBin;
+					val[v * 4 + c] = e4[c] & sub_mask;
 				}
 				const uint32_t i = base + kPartThreads * kVec + (uint32_t)v * kPartThreads + tid;
-				nxt[v] = i < n_vec ? src[i] : make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
+				nxt[v] = i < n_vec ? src[i] : make_uint4(0, 0, 0, 0);
 			}
-			part_round<kPartThreads, kVec * 4>(pl, pa.p1, bin, val, out, pa.regions1, g, pa.cap1, ovf STAMP_PASS);
+			part_round<kPartThreads, kVec * 4>(pl, out, bin0, g, bin, val, ovf STAMP_PASS);
 			__syncthreads();
 		}
 	}
-	part_finish<kPartThreads>(pl, pa.p1, out, cur, pa.regions1, g, pa.cap1, ovf);
+	part_finish<kPartThreads>(pl, out, bin0, g, ovf);
 }
 
 // ---- pass C --------------------------------------------------------------------------------------
-// one workgroup per segment; the segment's entries sit in `n_regions` regions of `cap` chunks each
+// one workgroup per segment (= input bin `seg`); pos_base + (seg << seg_shift | entry) is the
+// position reported for failed tests
 template <bool QUERY>
 __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
-                                                                 uint32_t seg_shift, const uint32_t* cur,
-                                                                 const uint32_t* ent, uint32_t cap,
-                                                                 uint32_t n_regions, const PartArgs pa)
+                                                                 uint32_t seg_shift, const PartIn in,
+                                                                 const PartSide sd)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	__shared__ uint32_t any;
 	const uint32_t tid = threadIdx.x;
-	const uint64_t seg = blockIdx.x;
+	const uint32_t seg = blockIdx.x;
+	const uint32_t n_regions = in.blocks * in.regions_per_block;
 	if (tid == 0)
 		any = 0;
 	__syncthreads();
 	uint32_t mine = 0;
 	for (uint32_t r = tid; r < n_regions; r += kApplyThreads)
-		mine |= cur[seg * n_regions + r];
+		mine |= in.cnt[part_in_region(in, seg, r)];
 	if (mine)
 		any = 1;
 	__syncthreads();
 	if (!any)
 		return; // untouched segment: no traffic at all
 	const uint64_t seg_bytes = 1ull << (seg_shift - 3);
-	const uint64_t byte0 = seg * seg_bytes;
+	const uint64_t byte0 = (uint64_t)seg * seg_bytes;
 	uint64_t nbytes = local_bytes - byte0;
 	if (nbytes > seg_bytes)
 		nbytes = seg_bytes;
@@ -447,23 +468,23 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 	__syncthreads();
 	uint32_t* lds = reinterpret_cast<uint32_t*>(dyn);
 	for (uint32_t r = 0; r < n_regions; ++r) {
-		const uint64_t reg = seg * n_regions + r;
-		uint32_t n_chunks = cur[reg];
-		if (n_chunks > cap)
-			n_chunks = cap;
-		const uint4* e4 = reinterpret_cast<const uint4*>(ent + reg * cap * kChunk);
-		const uint32_t n_ev = n_chunks * (kChunk / 4);
+		const uint32_t reg = part_in_region(in, seg, r);
+		uint32_t n = in.cnt[reg];
+		if (n > in.cap * kChunk)
+			n = in.cap * kChunk;
+		const uint4* e4 = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg * in.cap * kChunk);
+		const uint32_t n_ev = (n + 3) / 4;
 		for (uint32_t i = tid; i < n_ev; i += kApplyThreads) {
 			const uint4 q = e4[i];
 			const uint32_t e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
 			for (int c = 0; c < 4; ++c) {
-				if (e[c] == kSentinel)
+				if (i * 4 + c >= n)
 					continue;
 				if (!QUERY)
 					atomicOr(&lds[e[c] >> 5], 1u << (e[c] & 31));
 				else if (!((lds[e[c] >> 5] >> (e[c] & 31)) & 1u))
-					part_report_fail(pa, (seg << seg_shift) | e[c]);
+					part_report_fail(sd, sd.pos_base + (((uint64_t)seg << seg_shift) | e[c]));
 			}
 		}
 	}
@@ -503,7 +524,8 @@ bool part_hash_fits(const HashParams& hp_in, uint32_t p0)
 }
 
 template <int H, bool Q>
-static hipError_t launch_hash_h(const SeqArgs& a, const PartArgs& pa, unsigned blocks, size_t dyn, hipStream_t s)
+static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd,
+                                size_t dyn, hipStream_t s)
 {
 	const bool pow2 = a.mod.pow2 != 0, spaced = a.hp.n_seeds > 0;
 #define BTLBF_PLAUNCH(P, S)                                                                                  \
@@ -512,7 +534,8 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartArgs& pa, unsigned b
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);             \
 		if (e != hipSuccess)                                                                                 \
 			return e;                                                                                        \
-		hipLaunchKernelGGL((part_hash_kernel<H, P, S, Q>), dim3(blocks), dim3(kPartThreads), dyn, s, a, pa); \
+		hipLaunchKernelGGL((part_hash_kernel<H, P, S, Q>), dim3(out.regions), dim3(kPartThreads), dyn, s, a, \
+		                   out, bin_shift, sd);                                                              \
 	} while (0)
 	if (pow2 && !spaced)
 		BTLBF_PLAUNCH(true, false);
@@ -527,73 +550,77 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartArgs& pa, unsigned b
 }
 
 template <bool Q>
-static hipError_t launch_hash_q(const SeqArgs& a, const PartArgs& pa, unsigned blocks, size_t dyn, hipStream_t s)
+static hipError_t launch_hash_q(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd,
+                                size_t dyn, hipStream_t s)
 {
 	switch (a.hp.h) {
-	case 1: return launch_hash_h<1, Q>(a, pa, blocks, dyn, s);
-	case 2: return launch_hash_h<2, Q>(a, pa, blocks, dyn, s);
-	case 3: return launch_hash_h<3, Q>(a, pa, blocks, dyn, s);
-	case 4: return launch_hash_h<4, Q>(a, pa, blocks, dyn, s);
-	case 5: return launch_hash_h<5, Q>(a, pa, blocks, dyn, s);
-	case 6: return launch_hash_h<6, Q>(a, pa, blocks, dyn, s);
-	case 7: return launch_hash_h<7, Q>(a, pa, blocks, dyn, s);
-	case 8: return launch_hash_h<8, Q>(a, pa, blocks, dyn, s);
+	case 1: return launch_hash_h<1, Q>(a, out, bin_shift, sd, dyn, s);
+	case 2: return launch_hash_h<2, Q>(a, out, bin_shift, sd, dyn, s);
+	case 3: return launch_hash_h<3, Q>(a, out, bin_shift, sd, dyn, s);
+	case 4: return launch_hash_h<4, Q>(a, out, bin_shift, sd, dyn, s);
+	case 5: return launch_hash_h<5, Q>(a, out, bin_shift, sd, dyn, s);
+	case 6: return launch_hash_h<6, Q>(a, out, bin_shift, sd, dyn, s);
+	case 7: return launch_hash_h<7, Q>(a, out, bin_shift, sd, dyn, s);
+	case 8: return launch_hash_h<8, Q>(a, out, bin_shift, sd, dyn, s);
 	default: return hipErrorInvalidValue;
 	}
 }
 
 bool part_supported_h(uint32_t h) { return h >= 1 && h <= 8; }
 
-// pass A over tiles [a.first_tile, +a.n_tiles) (units: kPartTile windows); exactly pa.regions0
+// pass A over tiles [a.first_tile, +a.n_tiles) (units: kPartTile windows); exactly out.regions
 // workgroups are launched (one region each; idle ones still publish empty counts)
-hipError_t launch_part_hash(const SeqArgs& a_in, const PartArgs& pa, hipStream_t s)
+hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bin_shift, const PartSide& sd,
+                            int query, hipStream_t s)
 {
 	SeqArgs a = a_in;
 	if (a.n_tiles == 0)
 		return hipSuccess;
 	// LDS is nearly full with the staging rings: drop the positional table (Horner start-up
 	// instead) when it does not fit; spaced seeds cannot do without it
-	if (a.hp.n_seeds == 0 && part_hash_lds_bytes(a.hp, pa.p0) > kPartLdsBudget)
+	if (a.hp.n_seeds == 0 && part_hash_lds_bytes(a.hp, out.P) > kPartLdsBudget)
 		a.hp.use_pos_tab = 0;
-	const unsigned blocks = pa.regions0;
-	a.tiles_per_block = (a.n_tiles + blocks - 1) / blocks;
-	const size_t dyn = part_hash_lds_bytes(a.hp, pa.p0);
-	return pa.fail_count ? launch_hash_q<true>(a, pa, blocks, dyn, s) : launch_hash_q<false>(a, pa, blocks, dyn, s);
+	a.tiles_per_block = (a.n_tiles + out.regions - 1) / out.regions;
+	const size_t dyn = part_hash_lds_bytes(a.hp, out.P);
+	return query ? launch_hash_q<true>(a, out, bin_shift, sd, dyn, s)
+	             : launch_hash_q<false>(a, out, bin_shift, sd, dyn, s);
 }
 
-hipError_t launch_part_split(void* filter, const PartArgs& pa, hipStream_t s)
+hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t n_in_bins, const PartOut& out,
+                             uint32_t sub_shift, uint32_t in_shift, const PartSide& sd, int query, hipStream_t s)
 {
-	const size_t dyn = part_lds_bytes(pa.p1);
-	const void* fn = pa.fail_count ? reinterpret_cast<const void*>(&part_split_kernel<true>)
-	                               : reinterpret_cast<const void*>(&part_split_kernel<false>);
+	const size_t dyn = part_lds_bytes(out.P);
+	const void* fn = query ? reinterpret_cast<const void*>(&part_split_kernel<true>)
+	                       : reinterpret_cast<const void*>(&part_split_kernel<false>);
 	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 	if (e != hipSuccess)
 		return e;
-	if (pa.fail_count)
-		hipLaunchKernelGGL(part_split_kernel<true>, dim3(pa.p0 * pa.regions1), dim3(kPartThreads), dyn, s, filter, pa);
+	const uint32_t slices = out.regions;
+	const dim3 grid(n_in_bins * slices);
+	if (query)
+		hipLaunchKernelGGL(part_split_kernel<true>, grid, dim3(kPartThreads), dyn, s, filter, in, out, slices,
+		                   sub_shift, in_shift, sd);
 	else
-		hipLaunchKernelGGL(part_split_kernel<false>, dim3(pa.p0 * pa.regions1), dim3(kPartThreads), dyn, s, filter, pa);
+		hipLaunchKernelGGL(part_split_kernel<false>, grid, dim3(kPartThreads), dyn, s, filter, in, out, slices,
+		                   sub_shift, in_shift, sd);
 	return hipGetLastError();
 }
 
-hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs& pa, int test_only, hipStream_t s)
+hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_shift, uint64_t n_seg, const PartIn& in,
+                             const PartSide& sd, int query, hipStream_t s)
 {
-	const size_t dyn = (size_t)1 << (pa.seg_shift - 3);
-	const void* fn = test_only ? reinterpret_cast<const void*>(&part_apply_kernel<true>)
-	                           : reinterpret_cast<const void*>(&part_apply_kernel<false>);
+	const size_t dyn = (size_t)1 << (seg_shift - 3);
+	const void* fn = query ? reinterpret_cast<const void*>(&part_apply_kernel<true>)
+	                       : reinterpret_cast<const void*>(&part_apply_kernel<false>);
 	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 	if (e != hipSuccess)
 		return e;
-	const bool two = pa.levels == 2;
-	const uint32_t* cur = two ? pa.cur1 : pa.cur0;
-	const uint32_t* ent = two ? pa.out1 : pa.out0;
-	const uint32_t cap = two ? pa.cap1 : pa.cap0, regions = two ? pa.regions1 : pa.regions0;
-	if (test_only)
-		hipLaunchKernelGGL(part_apply_kernel<true>, dim3((unsigned)pa.n_seg), dim3(kApplyThreads), dyn, s,
-		                   static_cast<uint8_t*>(filter), local_bytes, pa.seg_shift, cur, ent, cap, regions, pa);
+	if (query)
+		hipLaunchKernelGGL(part_apply_kernel<true>, dim3((unsigned)n_seg), dim3(kApplyThreads), dyn, s,
+		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, in, sd);
 	else
-		hipLaunchKernelGGL(part_apply_kernel<false>, dim3((unsigned)pa.n_seg), dim3(kApplyThreads), dyn, s,
-		                   static_cast<uint8_t*>(filter), local_bytes, pa.seg_shift, cur, ent, cap, regions, pa);
+		hipLaunchKernelGGL(part_apply_kernel<false>, dim3((unsigned)n_seg), dim3(kApplyThreads), dyn, s,
+		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, in, sd);
 	return hipGetLastError();
 }
 
@@ -602,7 +629,8 @@ hipError_t launch_part_apply(void* filter, uint64_t local_bytes, const PartArgs&
 __global__ __launch_bounds__(256) void failset_build_kernel(const uint64_t* list, uint64_t n,
                                                            unsigned long long* table, uint64_t mask)
 {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+	     i += (uint64_t)gridDim.x * blockDim.x) {
 		const unsigned long long key = list[i] + 1;
 		uint64_t slot = mix64(key) & mask;
 		for (;;) {
@@ -614,7 +642,8 @@ __global__ __launch_bounds__(256) void failset_build_kernel(const uint64_t* list
 	}
 }
 
-hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t* table, uint64_t mask, hipStream_t s)
+hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t* table, uint64_t mask,
+                                hipStream_t s)
 {
 	if (n == 0)
 		return hipSuccess;
@@ -623,6 +652,36 @@ hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t*
 		blocks = 2048;
 	hipLaunchKernelGGL(failset_build_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fail_list, n,
 	                   reinterpret_cast<unsigned long long*>(table), mask);
+	return hipGetLastError();
+}
+
+// insert (test == 0) or test (test == 1) explicit GLOBAL positions (a spill list): positions outside
+// [lo, lo+len) are ignored; failed tests are appended to sd's fail list with their global position
+__global__ __launch_bounds__(256) void spill_kernel(uint32_t* words, const uint64_t* pos, uint64_t n, uint64_t lo,
+                                                   uint64_t len, int test, const PartSide sd)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+	     i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t lp = pos[i] - lo;
+		if (lp >= len)
+			continue;
+		if (!test)
+			bf_set(words, lp);
+		else if (!((bf_word(words, lp) >> (lp & 31)) & 1u))
+			part_report_fail(sd, pos[i]);
+	}
+}
+
+hipError_t launch_spill(void* filter, const uint64_t* pos, uint64_t n, uint64_t lo, uint64_t len, int test,
+                        const PartSide& sd, hipStream_t s)
+{
+	if (n == 0)
+		return hipSuccess;
+	uint64_t blocks = (n + 255) / 256;
+	if (blocks > 2048)
+		blocks = 2048;
+	hipLaunchKernelGGL(spill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint32_t*>(filter), pos, n,
+	                   lo, len, test, sd);
 	return hipGetLastError();
 }
 

@@ -229,6 +229,40 @@ int btlbf_test_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n,
                          void* stream);
 int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, unsigned hash_num,
                       uint64_t* hit_bits, int device, void* stream);
+/* ---- multi-GPU on the partitioned pipeline (large batches) -----------------------
+ * Needs a bit filter whose GLOBAL size and shard count are powers of two (2^29..2^42 bits).  The global
+ * position space is cut into 1024 level-0 bins; shard g owns bins [g*1024/n, (g+1)*1024/n).  All
+ * pointers are device pointers.
+ *  route_plan : byte sizes of ONE origin->owner block for a buffer of `plan_len` bytes.  Every rank
+ *               must plan with the same plan_len (e.g. the maximum over ranks) so that blocks have one
+ *               size and the exchange is a fixed-size all-to-all.
+ *  route_seqs : origin.  Hash the buffer and partition every probe position into the 1024 bins:
+ *               send_ent / send_cnt receive n_shards consecutive blocks (block g goes to shard g).
+ *               query != 0 additionally writes valid_bits and initialises hit_bits = valid_bits;
+ *               counts[0] (optional) = clean windows.  Entries that cannot be staged are appended to
+ *               spill_list as global positions (spill_count is zeroed by the call).
+ *  apply_routed: owner.  recv_ent / recv_cnt hold n_blocks blocks (one per origin, any order); they are
+ *               split down to segments and ORed into (query == 0) or tested against (query != 0) this
+ *               shard in LDS.  Positions found clear are appended to fail_list as GLOBAL positions
+ *               (fail_count must be zeroed by the caller).
+ *  apply_spill : owner.  Insert / test explicit global positions (the gathered spill lists); positions
+ *               of other shards are ignored.
+ *  resolve_seqs: origin.  Clear the hit bit of every window that owns one of the (gathered) failed
+ *               global positions. */
+int btlbf_route_plan(btlbf_filter* f, uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards,
+                     uint64_t* ent_bytes_per_shard, uint64_t* cnt_bytes_per_shard);
+int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
+                     uint64_t plan_len, unsigned n_shards, int query, void* send_ent, void* send_cnt,
+                     uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts, uint64_t* spill_list,
+                     uint64_t spill_cap, uint64_t* spill_count, void* stream);
+int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
+                       uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards, int query,
+                       uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream);
+int btlbf_apply_spill(btlbf_filter* f, const uint64_t* global_pos, uint64_t n, int query, uint64_t* fail_list,
+                      uint64_t fail_cap, uint64_t* fail_count, void* stream);
+int btlbf_resolve_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
+                       const uint64_t* fail_list, uint64_t n_fail, uint64_t* hit_bits, void* stream);
+
 /* number of set bits in a device buffer of nbytes (multiple of 8, e.g. a hit bitmap); synchronises the stream */
 int btlbf_popcount_bits(const void* dev_buf, uint64_t nbytes, uint64_t* out, int device, void* stream);
 
