@@ -193,7 +193,9 @@ def main():
     hit_bits = torch.zeros((n_bytes + 63) // 64, dtype=torch.int64, device=dev)
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
 
-    if world == 1:
+    force_sharded = bool(os.environ.get("BTLBF_BENCH_FORCE_SHARDED"))  # exercise the multi-GPU code path on one GPU
+    single = world == 1 and not force_sharded
+    if single:
         flt = m.BloomFilter(bits_per_gpu, H, K, device=local_rank)
         flt.setProfiling(True)
 
@@ -244,7 +246,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     barrier()
-    if world == 1:
+    if single:
         flt.getProfile(reset=True)  # drop the warm-up launches
     t0 = time.perf_counter()
     events = [step(True) for _ in range(args.steps)]
@@ -280,10 +282,11 @@ def main():
                                    "inserted then queried (all hits), reads resident in HBM"
                                    % (args.log2_bits, n_reads),
                        "filter_bits_total": bits_per_gpu * world, "kmers_per_pass": total_kmers,
-                       "parallelism": "1 GPU" if world == 1 else "hash-range shards x%d, RCCL all-to-all" % world},
+                       "parallelism": "1 GPU" if single else "hash-range shards x%d, partitioned routing, RCCL "
+                                      "all-to-all of 4-byte entries" % world},
             "insert_Mkmers_s": total_kmers / ins / 1e6, "query_Mkmers_s": total_kmers / qry / 1e6,
         }
-        if world == 1:
+        if single:
             prof = flt.getProfile(reset=True)
             filter_bytes = bits_per_gpu // 8
             kernels = {}

@@ -5,9 +5,16 @@ into `world` contiguous bit ranges; rank g holds bits [g*M/W, (g+1)*M/W) in its 
 positions are `hash % M` exactly as in the single-GPU filter (BloomFilter.hpp:190), so the shard
 bodies concatenated in rank order ARE the single-filter body (and the .bf file).
 
-    insert : every rank hashes its own reads (fused ntHash kernel) and buckets the h positions of
-             each k-mer by owning shard; ONE all-to-all moves shard-local positions to their owners;
-             owners atomicOr them into their bit range.
+Two data paths:
+  routed (default for power-of-two geometries, large batches): the global position space is cut into
+    1024 bins; each rank hashes its reads and radix-partitions the probe positions into those bins in
+    LDS (4-byte entries, 128-byte chunks); the block of bins a shard owns is contiguous, so ONE
+    fixed-size all-to-all moves it; the owner splits the received bins down to 64 KiB segments and
+    ORs / tests them in LDS.  A query sends nothing back but the few positions found clear
+    (all-gather of small fail lists); the origin clears the windows that own one of them.
+  direct (any geometry; the stand-in ops of the CPU tests):
+    insert : every rank buckets the h positions of each k-mer by owning shard; ONE all-to-all moves
+             shard-local positions to their owners; owners atomicOr them into their bit range.
     query  : all-to-all of positions out, owners test bits, all-to-all of one byte per probe back in
              the same order; the origin ANDs the h answers of each k-mer into the per-window bitmap.
 
@@ -90,6 +97,49 @@ class HipShardOps:
                                               self._sp()))
         return out.value
 
+    # ---- routing on the partitioned pipeline (btlbf_route_* / btlbf_apply_routed) ----
+    def _lay(self, read_len):
+        lay = _lib.Layout()
+        lay.starts, lay.n_seqs, lay.read_len = None, 0, read_len
+        return lay
+
+    def route_supported(self, global_bits, world):
+        pow2 = lambda x: x > 0 and (x & (x - 1)) == 0  # noqa: E731
+        return pow2(global_bits) and pow2(world) and (1 << 29) <= global_bits <= (1 << 42) and 1 <= self.h <= 8
+
+    def route_plan(self, plan_len, read_len):
+        e, c = C.c_uint64(), C.c_uint64()
+        lay = self._lay(read_len)
+        _lib.check(self.L.btlbf_route_plan(self.f, plan_len, C.byref(lay), self.world, C.byref(e), C.byref(c)))
+        return e.value, c.value
+
+    def route(self, reads, read_len, plan_len, query, send_ent, send_cnt, hit, valid, counts, spill, spill_count):
+        lay = self._lay(read_len)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _lib.check(self.L.btlbf_route_seqs(self.f, ptr(reads), reads.numel(), C.byref(lay), plan_len, self.world,
+                                           int(query), ptr(send_ent), ptr(send_cnt), ptr(hit), ptr(valid), ptr(counts),
+                                           ptr(spill), spill.numel(), ptr(spill_count), self._sp()))
+
+    def apply_routed(self, recv_ent, recv_cnt, n_blocks, plan_len, read_len, query, fail_list, fail_count):
+        lay = self._lay(read_len)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _lib.check(self.L.btlbf_apply_routed(self.f, ptr(recv_ent), ptr(recv_cnt), n_blocks, plan_len, C.byref(lay),
+                                             self.world, int(query), ptr(fail_list),
+                                             fail_list.numel() if fail_list is not None else 0, ptr(fail_count),
+                                             self._sp()))
+
+    def apply_spill(self, pos, query, fail_list, fail_count):
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _lib.check(self.L.btlbf_apply_spill(self.f, ptr(pos), pos.numel(), int(query), ptr(fail_list),
+                                            fail_list.numel() if fail_list is not None else 0, ptr(fail_count),
+                                            self._sp()))
+
+    def resolve(self, reads, read_len, fails, hit_bits):
+        lay = self._lay(read_len)
+        _lib.check(self.L.btlbf_resolve_seqs(self.f, C.c_void_p(reads.data_ptr()), reads.numel(), C.byref(lay),
+                                             C.c_void_p(fails.data_ptr()), fails.numel(), C.c_void_p(hit_bits.data_ptr()),
+                                             self._sp()))
+
     def local_body(self):
         import numpy as np
 
@@ -104,7 +154,7 @@ class HipShardOps:
 
 class ShardedBloomFilter:
     def __init__(self, global_bits, hash_num, kmer_size, device=0, group=None, ops=None, batch_reads=2_000_000,
-                 slack=1.25):
+                 slack=1.25, route=True, batch_bytes_cap=0):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -117,6 +167,8 @@ class ShardedBloomFilter:
                                                            device)
         self.batch_reads = batch_reads
         self.slack = slack
+        self.route_enabled = route         # use the partitioned routing path when the geometry allows
+        self.batch_bytes_cap = batch_bytes_cap
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         # gloo moves host memory: stage device tensors through the CPU (test mode only)
         self.stage_cpu = backend == "gloo"
@@ -165,8 +217,128 @@ class ShardedBloomFilter:
     def clear(self):
         self.ops.clear()
 
+    # ---- routed path: 4-byte partitioned entries, fixed-size all-to-all, owners apply in LDS ----
+    FAIL_CAP = 4 << 20   # failed positions one owner may report per batch (library limit for resolve)
+    SPILL_CAP = 1 << 20
+
+    def _routed(self):
+        return (self.route_enabled and hasattr(self.ops, "route_supported")
+                and self.ops.route_supported(self.bits, self.world))
+
+    def _max_over_ranks(self, v):
+        if self.world == 1:
+            return int(v)
+        t = torch.tensor([int(v)], dtype=torch.int64)
+        if not self.stage_cpu:
+            t = t.to(self.ops.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def _fixed_all_to_all(self, send):
+        if self.world == 1:
+            return send
+        if send.dtype == torch.uint8 and send.numel() % (8 * self.world) == 0:
+            # exchange 8-byte elements: keeps per-peer element counts far below 2^31
+            return self._fixed_all_to_all(send.view(torch.int64)).view(torch.uint8)
+        dev = send.device
+        if self.stage_cpu and send.is_cuda:
+            send = send.cpu()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        return recv.to(dev) if recv.device != dev else recv
+
+    def _all_gather_var(self, t, n):
+        """all-gather the first n elements of the 1-D int64 tensor t from every rank -> 1-D tensor"""
+        if self.world == 1:
+            return t[:n]
+        dev = t.device
+        cnt = torch.tensor([n], dtype=torch.int64, device="cpu" if self.stage_cpu else dev)
+        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
+        dist.all_gather(cnts, cnt, group=self.group)
+        cnts = [int(c.item()) for c in cnts]
+        m = max(cnts)
+        if m == 0:
+            return t[:0]
+        pad = torch.zeros(m, dtype=t.dtype, device="cpu" if self.stage_cpu else dev)
+        pad[:n] = t[:n].to(pad.device)
+        outs = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(outs, pad, group=self.group)
+        return torch.cat([o[:c] for o, c in zip(outs, cnts)]).to(dev)
+
+    def _route_batch_bytes(self, reads, read_len):
+        """bytes of read buffer per batch (same on every rank): four block-sets must fit in free HBM"""
+        longest = self._max_over_ranks(reads.numel())
+        if longest == 0:
+            return 0, 0
+        free = torch.cuda.mem_get_info(self.ops.device)[0] if self.ops.device.type == "cuda" else 1 << 40
+        # per read byte: h*(L-k+1)/L probes * 4 B per entry, ~1.1x capacity, send + recv + two split levels
+        per_byte = self.h * max(read_len - self.k + 1, 1) / read_len * 4 * 1.1 * 4.2
+        batch = int(0.7 * free / per_byte) // (64 * read_len) * (64 * read_len)
+        batch = max(batch, 64 * read_len)
+        if self.batch_bytes_cap:
+            batch = min(batch, self.batch_bytes_cap // (64 * read_len) * (64 * read_len) or 64 * read_len)
+        batch = min(batch, -(-longest // (64 * read_len)) * (64 * read_len))
+        return batch, -(-longest // batch)
+
+    def _routed_pass(self, reads, read_len, query, hit_bits=None, counts=None):
+        ops, W, dev = self.ops, self.world, self.ops.device
+        batch, n_batches = self._route_batch_bytes(reads, read_len)
+        if n_batches == 0:
+            return True
+        ent_b, cnt_b = ops.route_plan(batch, read_len)
+        send_ent = torch.empty(W * ent_b, dtype=torch.uint8, device=dev)
+        send_cnt = torch.empty(W * cnt_b, dtype=torch.uint8, device=dev)
+        spill = torch.empty(self.SPILL_CAP, dtype=torch.int64, device=dev)
+        spill_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        fail = torch.empty(self.FAIL_CAP, dtype=torch.int64, device=dev) if query else None
+        fail_count = torch.zeros(1, dtype=torch.int64, device=dev) if query else None
+        cnt2 = torch.zeros(2, dtype=torch.int64, device=dev) if query else None
+        n_valid = n_hit = 0
+        for bi in range(n_batches):
+            off = bi * batch
+            chunk = reads[off: off + batch]
+            view = None
+            if query:
+                w0, words = off // 64, (chunk.numel() + 63) // 64
+                view = hit_bits[w0: w0 + words]
+                fail_count.zero_()
+            if chunk.numel() == 0:  # this rank has run out of reads but still takes part in the exchange
+                chunk = reads[:0]
+            ops.route(chunk, read_len, batch, query, send_ent, send_cnt, view, None, cnt2, spill, spill_count)
+            recv_ent = self._fixed_all_to_all(send_ent)
+            recv_cnt = self._fixed_all_to_all(send_cnt)
+            ops.apply_routed(recv_ent, recv_cnt, W, batch, read_len, query, fail, fail_count)
+            # entries that could not be staged at their origin travel as explicit positions (rare)
+            n_spill = min(int(spill_count.item()), self.SPILL_CAP)
+            if int(spill_count.item()) > self.SPILL_CAP:
+                return False
+            gathered = self._all_gather_var(spill, n_spill)
+            if gathered.numel():
+                ops.apply_spill(gathered, query, fail, fail_count)
+            if query:
+                n_fail = int(fail_count.item())
+                over = self._max_over_ranks(1 if n_fail > self.FAIL_CAP else 0)
+                if over:
+                    return False  # a miss-heavy batch: the caller redoes the query on the direct path
+                fails = self._all_gather_var(fail, n_fail)
+                if fails.numel() > self.FAIL_CAP:
+                    return False
+                if fails.numel() and chunk.numel():
+                    ops.resolve(chunk, read_len, fails, view)
+                if counts is not None and chunk.numel():
+                    n_valid += int(cnt2[0].item())
+                    n_hit += ops.popcount_bits(view)
+        if query and counts is not None:
+            counts[0] = n_valid
+            counts[1] = n_hit
+        return True
+
     def insert_reads(self, reads, read_len):
         """insertSeq over this rank's uniform-length reads (flat uint8 tensor)"""
+        if self._routed():
+            if not self._routed_pass(reads, read_len, 0):
+                raise RuntimeError("routed insert: spill list overflow")
+            return
         for _, chunk in self._batches(reads, read_len):
             send, _, cnt, recv_cnt, _ = self._bucketed(chunk, read_len, False)
             mine = self._all_to_all(send, cnt, recv_cnt)
@@ -175,6 +347,10 @@ class ShardedBloomFilter:
     def contains_reads(self, reads, read_len, hit_bits, counts=None):
         """contains() of every window of this rank's reads -> hit_bits (int64 bitmap over the whole
         buffer, bit p = window at byte p); counts (optional int64[2]) = {clean windows, hits}"""
+        if self._routed():
+            if self._routed_pass(reads, read_len, 1, hit_bits, counts):
+                return hit_bits
+            # too many failed probes for the fail lists: fall through to the exact answer routing
         n_valid = n_hit = 0
         for off, chunk in self._batches(reads, read_len):
             send, stags, cnt, recv_cnt, valid = self._bucketed(chunk, read_len, True)

@@ -132,6 +132,42 @@ def gpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
     dist.destroy_process_group()
 
 
+def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len):
+    """the routed (partitioned) multi-GPU path with the real HIP kernels, all ranks on cuda:0"""
+    import btl_bloomfilter_amd as m
+    from btl_bloomfilter_amd.sharded import ShardedBloomFilter
+
+    torch.cuda.set_device(0)
+    _init(rank, world, port)
+    f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=4 << 20)  # several batches
+    assert f._routed()
+    mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
+    f.insert_reads(mine, read_len)
+    torch.cuda.synchronize()
+    dist.barrier()
+    np.save(os.path.join(outdir, "body%d.npy" % rank), f.ops.local_body())
+    # reference: the whole filter on this GPU, direct kernels
+    ref = m.BloomFilter(bits, h, k)
+    ref.setInsertMode("direct")
+    ref.setQueryMode("direct")
+    ref.insertSeqs(m.synth_reads_device(42, 0, world * n_reads, read_len), read_len=read_len)
+    res = {}
+    for name, q in (("hits", mine.clone()),
+                    ("few_misses", mine.clone()),
+                    ("many_misses", torch.cat([mine[: 3000 * read_len], m.synth_reads_device(43, rank * 50000, 50000, read_len)]))):
+        if name == "few_misses":
+            q.view(-1, read_len)[torch.arange(7, device="cuda") * 1000 + rank] = m.synth_reads_device(44, rank * 7, 7, read_len).view(7, read_len)
+        hit = torch.zeros((q.numel() + 63) // 64, dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int64)
+        f.contains_reads(q, read_len, hit, cnt)
+        eh, _, ec = ref.containsSeqs(q, read_len=read_len, want_valid=False, want_counts=True)
+        torch.cuda.synchronize()
+        res[name] = (bool((hit == eh).all().item()), cnt.tolist(), ec.cpu().tolist())
+    np.save(os.path.join(outdir, "res%d.npy" % rank), np.array([repr(res)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def free_port():
     import socket
 

@@ -11,7 +11,7 @@ import pytest
 import torch.multiprocessing as mp
 
 from conftest import load_golden
-from shard_helpers import cpu_worker, free_port, gpu_worker, sha
+from shard_helpers import cpu_worker, free_port, gpu_worker, gpu_worker_routed, sha
 
 
 def expected(oracle, bits, h, k, world, n_reads, L):
@@ -84,3 +84,23 @@ def test_sharded_hip_two_ranks_one_gpu(oracle, tmp_path):
         for j, r in enumerate(q.reshape(-1, L)):
             a, _ = oracle.bf_contains_seq_dense(got, bits, h, k, r.tobytes())
             assert (hit[j * L: j * L + len(a)] == a).all()
+
+
+@pytest.mark.gpu
+def test_sharded_routed_partitioned_two_ranks_one_gpu(tmp_path):
+    """routed path: pass A per origin, fixed-size exchange of 4-byte entries, owner splits + LDS apply;
+    queries return only failed positions.  Checked against the reference's golden digest and against
+    the single-GPU direct kernels (all-hit, few-miss and miss-heavy queries)."""
+    g = load_golden("digests.json")["bf_medium"]  # 200000 reads, 2^30 bits, k=31, h=4
+    bits, h, k, L, world = g["bits"], g["h"], g["k"], g["read_len"], 2
+    n_reads = g["n_reads"] // world
+    mp.spawn(gpu_worker_routed, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+    assert sha(got) == g["body_sha256"]
+    for rank in range(world):
+        res = eval(str(np.load(tmp_path / ("res%d.npy" % rank))[0]))
+        for name, (same, cnt, exp) in res.items():
+            assert same, (rank, name)
+            assert cnt == exp, (rank, name, cnt, exp)
+        assert res["hits"][1][0] == res["hits"][1][1] == n_reads * (L - k + 1)
+        assert res["few_misses"][1][1] < res["few_misses"][1][0]
