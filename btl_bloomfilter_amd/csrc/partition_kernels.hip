@@ -40,8 +40,7 @@ static constexpr uint32_t kPartLdsBudget = 160 * 1024 - 1024; // dynamic LDS a w
 // LDS image of the staged partitioner (carved from dynamic LDS by the kernels)
 struct PartLds {
 	uint32_t* stage;   // [P][SC] ring per bin, SC = kStageEntries / pow2ceil(P)
-	uint32_t* pt;      // [P] low 16 bits: ring write position (mod 2^16); high 16: entries in the ring
-	uint32_t* hist;    // [P] entries offered to the bin this round
+	uint32_t* pt;      // [P] low 16 bits: entries in the ring (+ offered this round); high 16: ring write position
 	uint32_t* fl;      // [P] entries flushed from the bin this round (multiple of 32)
 	uint32_t* written; // [P] chunks written to this workgroup's region of the bin
 	uint32_t* fout;    // [1024] output chunk index (inside the pass's output array) of each flush item
@@ -60,7 +59,7 @@ __host__ __device__ inline uint32_t part_pow2ceil(uint32_t x)
 
 __host__ __device__ inline uint32_t part_lds_bytes(uint32_t P)
 {
-	return kStageEntries * 4 + 4 * P * 4 + 1024 * 4 + 1024 * 2 + 16;
+	return kStageEntries * 4 + 3 * P * 4 + 1024 * 4 + 1024 * 2 + 16;
 }
 
 __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
@@ -68,8 +67,7 @@ __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
 	PartLds l;
 	l.stage = reinterpret_cast<uint32_t*>(base);
 	l.pt = l.stage + kStageEntries;
-	l.hist = l.pt + P;
-	l.fl = l.hist + P;
+	l.fl = l.pt + P;
 	l.written = l.fl + P;
 	l.fout = l.written + P;
 	l.flist = reinterpret_cast<uint16_t*>(l.fout + 1024);
@@ -86,7 +84,6 @@ __device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
 {
 	for (uint32_t b = threadIdx.x; b < P; b += NT) {
 		l.pt[b] = 0;
-		l.hist[b] = 0;
 		l.fl[b] = 0;
 		l.written[b] = 0;
 	}
@@ -123,10 +120,16 @@ static __device__ uint64_t g_stamp_out[16];
 
 // One round: every thread contributes E entries (bin[e] == kNoBin marks an empty slot) to the bins
 // [0, o.P) of this workgroup's output block; block-local bin b is global bin bin0 + b.
-// Precondition: hist[] all zero, fcount zero, and a barrier since they were written.
+// Precondition: fcount zero and a barrier since the previous round.
 // Region `region` of global bin g is chunks [(g*o.regions + region)*o.cap, +o.cap) of o.ent
 // (32-bit chunk indices: a pass's output holds fewer than 2^32 chunks).
 // `ovf(bin, val)` takes the entries that cannot be staged.
+//
+// pt[b] packs (ring write position << 16 | entries in the ring).  ONE returning LDS atomic per entry
+// adds 0x10001: the old value is the entry's ring slot (high half) and how many entries are ahead of
+// it (low half; fewer than SC means it fits now).  Entries that do not fit wait for this round's
+// flush; what still does not fit afterwards takes the overflow path and the write position is wound
+// back by their number (they are the last ones of the bin).
 template <int NT, int E, class OVF>
 __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
                                            const uint32_t (&bin)[E], const uint32_t (&val)[E], OVF&& ovf STAMP_ARGS)
@@ -134,38 +137,51 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	const uint32_t tid = threadIdx.x;
 	const uint32_t P = o.P;
 	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
-	uint32_t rank[E];
-	uint32_t staged = 0; // bit e: entry e found room in the ring before this round's flush
+	uint32_t old[E];
+	uint32_t late = 0; // bit e: entry e found no room before this round's flush
 	static_assert(E <= 32, "one flag bit per entry");
-#pragma unroll
-	for (int e = 0; e < E; ++e)
-		rank[e] = bin[e] != kNoBin ? atomicAdd(&l.hist[bin[e]], 1u) : 0;
-	__syncthreads();
-	STAMP(3);
-	// entries that fit behind what the ring already holds are staged now
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
 		if (bin[e] != kNoBin) {
-			const uint32_t w = l.pt[bin[e]];
-			if ((w >> 16) + rank[e] < SC) {
-				l.stage[(bin[e] << l.sc_shift) + ((w + rank[e]) & ring)] = val[e];
-				staged |= 1u << e;
-			}
+			old[e] = atomicAdd(&l.pt[bin[e]], 0x10001u);
+			if ((old[e] & 0xffffu) < SC)
+				l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 16) & ring)] = val[e];
+			else
+				late |= 1u << e;
 		}
 	}
 	__syncthreads();
 	STAMP(4);
-	// per bin: full chunks leave; their slots in this workgroup's region come from an LDS counter
-	for (uint32_t b = tid; b < P; b += NT) {
-		const uint32_t w = l.pt[b], occ = w >> 16;
-		const uint32_t tot = occ + l.hist[b];
-		const uint32_t avail = tot < SC ? tot : SC;
-		const uint32_t nfl = avail >> 5;
-		l.fl[b] = nfl << 5;
+	// per bin: full chunks leave; their slots in this workgroup's region come from an LDS counter.
+	// The reservation of flush-list slots is aggregated per wave (one LDS atomic per wave).
+	for (uint32_t b0 = 0; b0 < P; b0 += NT) {
+		const uint32_t b = b0 + tid;
+		uint32_t nfl = 0, w = 0, occ = 0;
+		if (b < P) {
+			w = l.pt[b];
+			occ = w & 0xffffu; // ring content + everything offered this round
+			const uint32_t avail = occ < SC ? occ : SC;
+			nfl = avail >> 5;
+			l.fl[b] = nfl << 5;
+		}
+		// exclusive prefix sum of nfl over the wave
+		uint32_t incl = nfl;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(incl, d, 64);
+			if ((tid & 63) >= (uint32_t)d)
+				incl += t;
+		}
+		const uint32_t total = __shfl(incl, 63, 64);
+		uint32_t base = 0;
+		if ((tid & 63) == 63 && total)
+			base = atomicAdd(l.fcount, total);
+		base = __shfl(base, 63, 64) + incl - nfl;
 		if (nfl) {
-			const uint32_t base = atomicAdd(l.fcount, nfl);
 			const uint32_t w0 = l.written[b];
-			const uint32_t hc = ((w - occ) & ring) >> 5; // ring chunk at the read position
+			// the ring's read position: write position minus content, before this round's additions
+			// are accounted for -- both halves of pt grew by the same amount, so their difference is it
+			const uint32_t hc = (((w >> 16) - occ) & ring) >> 5;
 			const uint32_t o0 = ((bin0 + b) * o.regions + region) * o.cap;
 			for (uint32_t c = 0; c < nfl; ++c) {
 				l.flist[base + c] = (uint16_t)(b | (((hc + c) & (ring >> 5)) << 10));
@@ -197,25 +213,25 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	__syncthreads();
 	STAMP(6);
 	// entries that did not fit before the flush: into the freed ring space, else overflow
+	if (late) {
 #pragma unroll
-	for (int e = 0; e < E; ++e) {
-		if (bin[e] != kNoBin && !((staged >> e) & 1)) {
-			const uint32_t w = l.pt[bin[e]];
-			if ((w >> 16) + rank[e] - l.fl[bin[e]] < SC)
-				l.stage[(bin[e] << l.sc_shift) + ((w + rank[e]) & ring)] = val[e];
-			else
-				ovf(bin[e], val[e]);
+		for (int e = 0; e < E; ++e) {
+			if ((late >> e) & 1) {
+				if ((old[e] & 0xffffu) - l.fl[bin[e]] < SC)
+					l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 16) & ring)] = val[e];
+				else
+					ovf(bin[e], val[e]);
+			}
 		}
 	}
 	__syncthreads();
 	STAMP(7);
 	for (uint32_t b = tid; b < P; b += NT) {
-		const uint32_t w = l.pt[b], occ = w >> 16, f = l.fl[b];
-		const uint32_t tot = occ + l.hist[b] - f;  // wants to be in the ring after the flush
-		const uint32_t nocc = tot < SC ? tot : SC; // entries beyond took the overflow path
-		const uint32_t accepted = nocc + f - occ;
-		l.pt[b] = ((w + accepted) & 0xffffu) | (nocc << 16);
-		l.hist[b] = 0;
+		const uint32_t w = l.pt[b], f = l.fl[b];
+		const uint32_t tot = (w & 0xffffu) - f;    // wants to be in the ring after the flush
+		const uint32_t nocc = tot < SC ? tot : SC; // entries beyond took the overflow path ...
+		const uint32_t wpos = (w >> 16) - (tot - nocc); // ... and give their ring slots back
+		l.pt[b] = (wpos << 16) | nocc;
 	}
 	if (tid == 0)
 		*l.fcount = 0;
@@ -232,7 +248,7 @@ __device__ __forceinline__ void part_finish(const PartLds& l, const PartOut& o, 
 	const uint32_t tid = threadIdx.x, lane32 = tid & 31;
 	const uint32_t ring = (1u << l.sc_shift) - 1;
 	for (uint32_t b = tid >> 5; b < o.P; b += NT / 32) {
-		const uint32_t w = l.pt[b], n = w >> 16, hd = (w - n) & ring;
+		const uint32_t w = l.pt[b], n = w & 0xffffu, hd = ((w >> 16) - n) & ring;
 		const uint32_t w0 = l.written[b];
 		const uint32_t full = w0 < o.cap ? w0 : o.cap; // chunks of this region that really hold data
 		const uint32_t o0 = ((bin0 + b) * o.regions + region) * o.cap;
