@@ -102,6 +102,20 @@ __device__ __forceinline__ void seq_setup_tables(SeqShared& sh, const HashParams
 // Stage the tile that starts at byte offset g0.  Ends with a __syncthreads(); begins with one so
 // that the previous tile has been fully consumed.  tile_off = g0 % read_len (uniform layout only).
 // Returns the misalignment `mis`: LDS index of window w's first base is w + mis.
+// x mod L for x < 2^24, L >= 1, without a divide: inv = floor((2^32-1)/L)
+__device__ __forceinline__ uint32_t small_mod(uint32_t x, uint32_t L, uint32_t inv)
+{
+	uint32_t r = x - __umulhi(x, inv) * L;
+	while (r >= L)
+		r -= L;
+	return r;
+}
+
+// Stage the tile that starts at byte offset g0: every thread converts aligned 4-byte words of the
+// read buffer (coalesced loads) through the LUT and writes them to LDS, so all waves share the work.
+// Ends with a __syncthreads(); begins with one so that the previous tile has been fully consumed.
+// tile_off = g0 % read_len (uniform layout only).  Returns the misalignment `mis` (0..3): the LDS
+// index of window w's first base is w + mis.
 template <int NT, int KW = kW>
 __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_cap, SeqShared& sh,
                                                    const uint8_t* seq, uint64_t len, const LayoutParams& lay,
@@ -111,46 +125,40 @@ __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_
 	const uint32_t tid = threadIdx.x;
 	const uint32_t L = lay.read_len;
 	const uint64_t* starts = lay.starts;
-	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(seq + g0) & 15);
+	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(seq + g0) & 3);
 	uint64_t need = len - g0;
 	if (need > (uint64_t)(kTileW + k - 1))
 		need = kTileW + k - 1;
-	const uint32_t n_chunks = (mis + (uint32_t)need + 15) / 16;
+	const uint32_t n_words = (mis + (uint32_t)need + 3) / 4;
+	const bool uniform = !starts && L;
+	const uint32_t inv = uniform ? 0xffffffffu / L : 0;
 	__syncthreads(); // previous tile fully consumed (and tables written, first time round)
 
-	// chunks past the data are zero-filled so no stale flags survive
-	for (uint32_t j = tid; j < tile_cap / 16; j += NT) {
-		uint4 raw = make_uint4(0, 0, 0, 0);
-		if (j < n_chunks)
-			raw = *reinterpret_cast<const uint4*>(seq + g0 - mis + 16ull * j);
-		const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
-		// position of this chunk's first byte relative to g0 (negative for the misaligned head)
-		const int32_t rel0 = (int32_t)(16 * j) - (int32_t)mis;
-		uint32_t r = 0; // (offset within read) of the chunk's first byte, uniform layout only
-		if (!starts && L) {
-			const uint32_t m = mis % L;
-			r = ((tile_off + 16 * j) % L + L - m) % L;
-		}
-		uint32_t outw[4];
+	// words past the data are zero-filled so no stale flags survive
+	for (uint32_t j = tid; j < tile_cap / 4; j += NT) {
+		uint32_t raw = 0;
+		if (j < n_words)
+			raw = *reinterpret_cast<const uint32_t*>(seq + g0 - mis + 4ull * j);
+		// position of this word's first byte relative to g0 (negative for the misaligned head)
+		const int32_t rel0 = (int32_t)(4 * j) - (int32_t)mis;
+		uint32_t r = 0; // offset within its read of the word's first byte (uniform layout only)
+		if (uniform)
+			r = small_mod(tile_off + 4 * j + 4 * L - mis, L, inv);
+		uint32_t o = 0;
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			uint32_t o = 0;
-#pragma unroll
-			for (int b = 0; b < 4; ++b) {
-				const int32_t rel = rel0 + q * 4 + b;
-				uint32_t e = sh.lut[(wv[q] >> (8 * b)) & 0xff];
-				if (rel < 0 || (uint64_t)rel >= need)
-					e = 0;
-				if (!starts && L) {
-					if (r == 0)
-						e |= kBaseStart;
-					r = (r + 1 == L) ? 0 : r + 1;
-				}
-				o |= e << (8 * b);
+		for (int b = 0; b < 4; ++b) {
+			const int32_t rel = rel0 + b;
+			uint32_t e = sh.lut[(raw >> (8 * b)) & 0xff];
+			if (rel < 0 || (uint64_t)rel >= need)
+				e = 0;
+			if (uniform) {
+				if (r == 0)
+					e |= kBaseStart;
+				r = (r + 1 == L) ? 0 : r + 1;
 			}
-			outw[q] = o;
+			o |= e << (8 * b);
 		}
-		*reinterpret_cast<uint4*>(tile + 16 * j) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+		reinterpret_cast<uint32_t*>(tile)[j] = o;
 	}
 	if (starts) {
 		// first index s with starts[s] > g0: every boundary strictly inside (g0, g0+need) matters
