@@ -60,6 +60,7 @@ _PROTOS = {
     "btlbf_upload": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     "btlbf_download": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     "btlbf_set_insert_mode": (C.c_int, [_P, C.c_int, C.c_uint64]),
+    "btlbf_release_scratch": (C.c_int, [_P]),
     "btlbf_set_profiling": (C.c_int, [_P, C.c_int]),
     "btlbf_get_profile": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint), C.c_int]),
     "btlbf_set_query_mode": (C.c_int, [_P, C.c_int]),

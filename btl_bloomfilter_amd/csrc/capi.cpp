@@ -575,6 +575,17 @@ extern "C" int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch
 	return BTLBF_OK;
 }
 
+extern "C" int btlbf_release_scratch(btlbf_filter* f)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	DeviceGuard g(f->device);
+	(void)hipFree(f->d_part); // synchronises with work in flight
+	f->d_part = nullptr;
+	f->part_bytes = 0;
+	return BTLBF_OK;
+}
+
 extern "C" int btlbf_set_profiling(btlbf_filter* f, int on)
 {
 	if (!f)

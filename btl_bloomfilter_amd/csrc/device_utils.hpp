@@ -116,26 +116,6 @@ __device__ __forceinline__ bool cbf_cas_byte(uint32_t* words, uint64_t lp, uint3
 	}
 }
 
-// incrementMin (CountingBloomFilter.hpp:135-162) on local positions lp[0..h)
-template <int MAXH>
-__device__ __forceinline__ void cbf_increment_min(uint32_t* words, const uint64_t* lp, uint32_t h)
-{
-	for (;;) {
-		uint32_t mn = 0xffu;
-		for (uint32_t i = 0; i < h; ++i) {
-			uint32_t v = cbf_read_fresh(words, lp[i]);
-			mn = v < mn ? v : mn;
-		}
-		if (mn == 0xffu)
-			return; // minVal + 1 would wrap
-		bool done = false;
-		for (uint32_t i = 0; i < h; ++i)
-			done |= cbf_cas_byte(words, lp[i], mn);
-		if (done)
-			return;
-	}
-}
-
 __device__ __forceinline__ uint64_t mix64(uint64_t z)
 {
 	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -57,13 +57,17 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
 
 		uint32_t valid_mask = 0, hit_mask = 0;
-		// contains() with <= kPipe hashes keeps every probe of the lane's kW windows in flight at
-		// once (kW*h independent loads); larger hash counts take the per-window path.
+		// contains() with <= kPipe hashes runs in two waves of independent loads per lane: probe 0
+		// of all kW windows first (like the reference's early exit at the first clear bit,
+		// BloomFilter.hpp:257-259, a k-mer that misses here costs one request instead of h), then
+		// probes 1..h-1 of the windows that are still alive.  Larger hash counts take the per-window path.
 		constexpr int kPipe = 4;
 		uint32_t wordbuf[kW][kPipe];
 		uint32_t bitbuf[kW][kPipe];
+		uint64_t canon[kW];
 		(void)wordbuf;
 		(void)bitbuf;
+		(void)canon;
 		const bool pipelined = (OP == OP_BF_CONTAINS) && !SPACED && h <= kPipe;
 
 		seq_lane_windows<SPACED, kW>(tile, sh, a.hp, spaced_lds, tid * kW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
@@ -97,15 +101,11 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 			} else if (OP == OP_BF_CONTAINS) {
 				const uint32_t* words = static_cast<const uint32_t*>(a.filter);
 				if (pipelined) {
-#pragma unroll
-					for (int i = 0; i < kPipe; ++i) {
-						if ((uint32_t)i < h) {
-							const uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
-							// unclean windows probe word 0 (harmless) so the loop stays branch-free
-							wordbuf[w][i] = bf_word(words, ok ? p : 0);
-							bitbuf[w][i] = (uint32_t)p & 31;
-						}
-					}
+					const uint64_t p = reduce_mod<POW2>(wh.bcan, a.mod);
+					// unclean windows probe word 0 (harmless) so the loop stays branch-free
+					wordbuf[w][0] = bf_word(words, ok ? p : 0);
+					bitbuf[w][0] = (uint32_t)p & 31;
+					canon[w] = wh.bcan;
 				} else if (ok) {
 					uint32_t all = 1;
 					for (uint32_t i = 0; i < h; ++i) {
@@ -203,13 +203,34 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 		});
 
 		if (OP == OP_BF_CONTAINS && pipelined) {
+			const uint32_t* words = static_cast<const uint32_t*>(a.filter);
+			uint32_t alive = 0;
+#pragma unroll
+			for (int w = 0; w < kW; ++w)
+				alive |= ((valid_mask >> w) & (wordbuf[w][0] >> bitbuf[w][0]) & 1u) << w;
+			// second wave: the remaining probes of the windows whose first bit was set
 #pragma unroll
 			for (int w = 0; w < kW; ++w) {
-				uint32_t all = (valid_mask >> w) & 1u;
+				if ((alive >> w) & 1u) {
 #pragma unroll
-				for (int i = 0; i < kPipe; ++i)
-					if ((uint32_t)i < h)
-						all &= wordbuf[w][i] >> bitbuf[w][i];
+					for (int i = 1; i < kPipe; ++i) {
+						if ((uint32_t)i < h) {
+							const uint64_t p = reduce_mod<POW2>(extra_hash(canon[w], a.hp.kms, i), a.mod);
+							wordbuf[w][i] = bf_word(words, p);
+							bitbuf[w][i] = (uint32_t)p & 31;
+						}
+					}
+				}
+			}
+#pragma unroll
+			for (int w = 0; w < kW; ++w) {
+				uint32_t all = (alive >> w) & 1u;
+				if (all) {
+#pragma unroll
+					for (int i = 1; i < kPipe; ++i)
+						if ((uint32_t)i < h)
+							all &= wordbuf[w][i] >> bitbuf[w][i];
+				}
 				hit_mask |= (all & 1u) << w;
 			}
 		}

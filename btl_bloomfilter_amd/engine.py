@@ -155,6 +155,9 @@ class _Filter:
         m = {"auto": 0, "direct": 1, "partitioned": 2}[mode] if isinstance(mode, str) else int(mode)
         check(self._L.btlbf_set_insert_mode(self._h, m, int(scratch_bytes)))
 
+    def releaseScratch(self):
+        check(self._L.btlbf_release_scratch(self._h))
+
     def setProfiling(self, on=True):
         check(self._L.btlbf_set_profiling(self._h, int(bool(on))))
 

@@ -130,6 +130,9 @@ int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch_bytes);
  * every k-mer hits (a batch with many misses is redone by the direct gather kernel).  AUTO samples
  * the batch first.  Results are identical in every mode.  Environment: BTLBF_QUERY_MODE. */
 int btlbf_set_query_mode(btlbf_filter* f, int mode);
+/* The partitioned paths keep their scratch allocation (up to 80 % of the HBM that was free at first
+ * use, or the cap given to btlbf_set_insert_mode) cached in the filter; this returns it. */
+int btlbf_release_scratch(btlbf_filter* f);
 
 /* Per-kernel timing for measurement harnesses: when on, every kernel the sequence calls launch is
  * bracketed by HIP events on the launch stream.  btlbf_get_profile synchronises those events and
