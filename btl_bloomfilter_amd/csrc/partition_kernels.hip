@@ -140,15 +140,19 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	uint32_t old[E];
 	uint32_t late = 0; // bit e: entry e found no room before this round's flush
 	static_assert(E <= 32, "one flag bit per entry");
+	// all E atomics of the lane are issued back to back (independent), then consumed
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
-		if (bin[e] != kNoBin) {
+		old[e] = 0xffffu; // "no room": empty slots fall through both tests below
+		if (bin[e] != kNoBin)
 			old[e] = atomicAdd(&l.pt[bin[e]], 0x10001u);
-			if ((old[e] & 0xffffu) < SC)
-				l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 16) & ring)] = val[e];
-			else
-				late |= 1u << e;
-		}
+	}
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		if ((old[e] & 0xffffu) < SC)
+			l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 16) & ring)] = val[e];
+		else if (bin[e] != kNoBin)
+			late |= 1u << e;
 	}
 	__syncthreads();
 	STAMP(4);
@@ -316,7 +320,6 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 	uint32_t* words = static_cast<uint32_t*>(a.filter);
 	const uint32_t ent_mask = bin_shift >= 32 ? 0xffffffffu : (1u << bin_shift) - 1;
 	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, ((uint64_t)b << bin_shift) | v); };
-	const bool sharded = a.mod.shard_len != a.mod.size;
 	const uint64_t out_bytes = ((a.len + 63) / 64) * 8;
 	uint32_t my_valid = 0;
 
@@ -344,12 +347,10 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 			vmask |= (uint32_t)ok << w;
 #pragma unroll
 			for (int i = 0; i < H; ++i) {
-				uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
-				bool mine = ok;
-				if (sharded) { // wave-uniform
-					p -= a.mod.shard_lo;
-					mine = ok && p < a.mod.shard_len;
-				}
+				// positions outside this GPU's window (a shard) are dropped; without sharding the
+				// window is the whole filter and the test is always true
+				const uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod) - a.mod.shard_lo;
+				const bool mine = ok && p < a.mod.shard_len;
 				bin[w * H + i] = mine ? (uint32_t)(p >> bin_shift) : kNoBin;
 				val[w * H + i] = (uint32_t)p & ent_mask;
 			}
