@@ -1354,7 +1354,8 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 // A, regions = its CU count); the block of one owner is contiguous, so the exchange is a fixed-size
 // all-to-all of [1024/W bins][regions][cap][32] uint32 plus the entry counts.
 struct RoutePlan {
-	uint32_t shift0 = 0; // log2(positions per level-0 bin)
+	uint32_t bins = 1024; // level-0 bins over the global position space
+	uint32_t shift0 = 0;  // log2(positions per level-0 bin)
 	uint32_t bins_per_shard = 0;
 	uint32_t regions = 0;
 	uint32_t cap = 0;
@@ -1368,15 +1369,22 @@ int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, uns
 		return fail(BTLBF_EINVAL, "routing needs a bit filter whose global size and shard count are powers of two");
 	if (!part_supported_h(f->hp.h) || !part_hash_fits(f->hp, 1024))
 		return fail(BTLBF_EINVAL, "routing does not support this hash configuration");
-	const unsigned lm = ceil_log2(M);
-	if (lm < 10 + 19 || lm - 10 > 32)
+	// BTLBF_ROUTE_BINS (power of two, default 1024) exists for tests: fewer level-0 bins make small
+	// filters exercise the two-split and 32-bit-entry geometries of a 1 TiB filter on 8 GPUs
+	if (const char* e = getenv("BTLBF_ROUTE_BINS")) {
+		const unsigned b = (unsigned)atoi(e);
+		if (b >= n_shards && b <= 1024 && !(b & (b - 1)))
+			rp.bins = b;
+	}
+	const unsigned lm = ceil_log2(M), lb = ceil_log2(rp.bins);
+	if (lm < lb + 19 || lm - lb > 32 || rp.bins < n_shards)
 		return fail(BTLBF_EINVAL, "routing supports global filters of 2^29 .. 2^42 bits");
-	rp.shift0 = lm - 10;
-	rp.bins_per_shard = 1024 / n_shards;
+	rp.shift0 = lm - lb;
+	rp.bins_per_shard = rp.bins / n_shards;
 	rp.regions = cu_count(f->device);
 	const uint64_t tile_w = (uint64_t)part_tile_windows();
 	const double entries = (double)((len + tile_w - 1) / tile_w) * probes_per_tile(f, lay);
-	rp.cap = chunks_for(entries / (1024.0 * rp.regions), 1);
+	rp.cap = chunks_for(entries / ((double)rp.bins * rp.regions), 1);
 	rp.ent_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * rp.cap * 128;
 	rp.cnt_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * 4;
 	return BTLBF_OK;
@@ -1430,7 +1438,7 @@ extern "C" int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, 
 	const uint64_t tile_w = (uint64_t)part_tile_windows();
 	a.first_tile = 0;
 	a.n_tiles = (len + tile_w - 1) / tile_w;
-	PartOut out{1024, rp.regions, rp.cap, static_cast<uint32_t*>(send_cnt), static_cast<uint32_t*>(send_ent)};
+	PartOut out{rp.bins, rp.regions, rp.cap, static_cast<uint32_t*>(send_cnt), static_cast<uint32_t*>(send_ent)};
 	PartSide sd;
 	memset(&sd, 0, sizeof sd);
 	sd.spill_list = spill_list;

@@ -132,8 +132,10 @@ def gpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
     dist.destroy_process_group()
 
 
-def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len):
+def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, route_bins=0):
     """the routed (partitioned) multi-GPU path with the real HIP kernels, all ranks on cuda:0"""
+    if route_bins:
+        os.environ["BTLBF_ROUTE_BINS"] = str(route_bins)
     import btl_bloomfilter_amd as m
     from btl_bloomfilter_amd.sharded import ShardedBloomFilter
 

@@ -104,3 +104,30 @@ def test_sharded_routed_partitioned_two_ranks_one_gpu(tmp_path):
             assert cnt == exp, (rank, name, cnt, exp)
         assert res["hits"][1][0] == res["hits"][1][1] == n_reads * (L - k + 1)
         assert res["few_misses"][1][1] < res["few_misses"][1][0]
+
+
+@pytest.mark.gpu
+def test_sharded_routed_two_split_levels_and_32bit_entries(tmp_path):
+    """the owner-side geometry of a 1 TiB filter on 8 GPUs (32-bit entries, two split passes),
+    reproduced at 2^36 bits on 2 ranks by using only 16 level-0 bins (BTLBF_ROUTE_BINS)"""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs ~30 GiB of HBM")
+    bits, h, k, L, world, n_reads = 1 << 36, 4, 31, 150, 2, 60000
+    mp.spawn(gpu_worker_routed, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L, 16), nprocs=world, join=True)
+    for rank in range(world):
+        res = eval(str(np.load(tmp_path / ("res%d.npy" % rank))[0]))
+        for name, (same, cnt, exp) in res.items():
+            assert same, (rank, name)
+            assert cnt == exp, (rank, name, cnt, exp)
+    # shard bodies against a single filter built by the direct kernel
+    import btl_bloomfilter_amd as m
+
+    ref = m.BloomFilter(bits, h, k)
+    ref.setInsertMode("direct")
+    ref.insertSeqs(m.synth_reads_device(42, 0, world * n_reads, L), read_len=L)
+    body = ref.download()
+    got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+    assert (got == body).all()
