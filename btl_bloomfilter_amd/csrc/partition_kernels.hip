@@ -43,9 +43,8 @@ struct PartLds {
 	uint32_t* pt;      // [P] low 16 bits: entries in the ring (+ offered this round); high 16: ring write position
 	uint32_t* fl;      // [P] entries flushed from the bin this round (multiple of 32)
 	uint32_t* written; // [P] chunks written to this workgroup's region of the bin
-	uint32_t* fout;    // [1024] output chunk index (inside the pass's output array) of each flush item
-	uint16_t* flist;   // [1024] flush items: bin | ring chunk << 10
-	uint32_t* fcount;
+	uint32_t* fout;    // [1024] flush items, a private slice per wave: output chunk index ...
+	uint16_t* flist;   // [1024] ... and bin | ring chunk << 10
 	uint32_t sc_shift; // log2(SC)
 };
 
@@ -71,7 +70,6 @@ __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
 	l.written = l.fl + P;
 	l.fout = l.written + P;
 	l.flist = reinterpret_cast<uint16_t*>(l.fout + 1024);
-	l.fcount = reinterpret_cast<uint32_t*>(l.flist + 1024);
 	uint32_t pc = part_pow2ceil(P < 32 ? 32 : P), sh = 0;
 	while ((kStageEntries >> sh) > pc)
 		++sh; // kStageEntries / 2^sh == pc  ->  SC = 2^sh
@@ -87,8 +85,6 @@ __device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
 		l.fl[b] = 0;
 		l.written[b] = 0;
 	}
-	if (threadIdx.x == 0)
-		*l.fcount = 0;
 }
 
 #ifdef BTLBF_PHASE_STAMPS
@@ -120,16 +116,22 @@ static __device__ uint64_t g_stamp_out[16];
 
 // One round: every thread contributes E entries (bin[e] == kNoBin marks an empty slot) to the bins
 // [0, o.P) of this workgroup's output block; block-local bin b is global bin bin0 + b.
-// Precondition: fcount zero and a barrier since the previous round.
 // Region `region` of global bin g is chunks [(g*o.regions + region)*o.cap, +o.cap) of o.ent
 // (32-bit chunk indices: a pass's output holds fewer than 2^32 chunks).
 // `ovf(bin, val)` takes the entries that cannot be staged.
 //
-// pt[b] packs (ring write position << 16 | entries in the ring).  ONE returning LDS atomic per entry
-// adds 0x10001: the old value is the entry's ring slot (high half) and how many entries are ahead of
-// it (low half; fewer than SC means it fits now).  Entries that do not fit wait for this round's
-// flush; what still does not fit afterwards takes the overflow path and the write position is wound
-// back by their number (they are the last ones of the bin).
+// pt[b] packs (ring write position << 16 | entries in the ring).  Three phases, two barriers:
+//  1. ONE returning LDS atomic per entry adds 0x10001: the old value is the entry's ring slot (high
+//     half) and how many entries are ahead of it (low half; fewer than SC means it fits and is written
+//     now; otherwise it is "late").
+//  2. the lane that owns bin b (b = lane index) sees how much arrived, copies the bin's full 32-entry
+//     chunks from the ring to this workgroup's region (one aligned 128-byte line each) and already
+//     writes the bin's state for the next round: what the late entries will do is determined by
+//     their old values alone (those still beyond the ring after the flush overflow and give their
+//     slots back), so nothing has to wait for them.
+//  3. late entries move into the ring space the flush freed, or overflow.
+// No barrier is needed after phase 3: the next round's phase 1 only touches pt (final since phase 2)
+// and ring slots behind the late ones; its phase 2 comes after its own barrier.
 template <int NT, int E, class OVF>
 __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
                                            const uint32_t (&bin)[E], const uint32_t (&val)[E], OVF&& ovf STAMP_ARGS)
@@ -156,61 +158,61 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	}
 	__syncthreads();
 	STAMP(4);
-	// per bin: full chunks leave; their slots in this workgroup's region come from an LDS counter.
-	// The reservation of flush-list slots is aggregated per wave (one LDS atomic per wave).
-	for (uint32_t b0 = 0; b0 < P; b0 += NT) {
-		const uint32_t b = b0 + tid;
-		uint32_t nfl = 0, w = 0, occ = 0;
+	{
+		// bins are owned by lanes (P <= NT): wave v owns bins [64v, 64v+64) and flushes them itself,
+		// through its private slice of the flush list -- no workgroup barrier in between
+		const uint32_t b = tid, lane = tid & 63;
+		uint32_t nfl = 0, hc = 0, o0 = 0, w0 = 0;
 		if (b < P) {
-			w = l.pt[b];
-			occ = w & 0xffffu; // ring content + everything offered this round
-			const uint32_t avail = occ < SC ? occ : SC;
+			const uint32_t w = l.pt[b];
+			const uint32_t occ = w & 0xffffu;           // ring content + everything offered this round
+			const uint32_t avail = occ < SC ? occ : SC; // entries that really sit in the ring
 			nfl = avail >> 5;
-			l.fl[b] = nfl << 5;
+			const uint32_t f = nfl << 5;
+			// state for the next round (see above)
+			const uint32_t tot = occ - f;
+			const uint32_t nocc = tot < SC ? tot : SC;
+			l.pt[b] = (((w >> 16) - (tot - nocc)) << 16) | nocc;
+			l.fl[b] = f;
+			if (nfl) {
+				w0 = l.written[b];
+				l.written[b] = w0 + nfl;
+				// read position of the ring: both halves of pt grew by the same amount this round
+				hc = (((w >> 16) - occ) & ring) >> 5;
+				o0 = ((bin0 + b) * o.regions + region) * o.cap;
+			}
 		}
-		// exclusive prefix sum of nfl over the wave
+		// exclusive prefix sum of nfl over the wave -> slots in the wave's slice (2*SC items)
 		uint32_t incl = nfl;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
 			const uint32_t t = __shfl_up(incl, d, 64);
-			if ((tid & 63) >= (uint32_t)d)
+			if (lane >= (uint32_t)d)
 				incl += t;
 		}
 		const uint32_t total = __shfl(incl, 63, 64);
-		uint32_t base = 0;
-		if ((tid & 63) == 63 && total)
-			base = atomicAdd(l.fcount, total);
-		base = __shfl(base, 63, 64) + incl - nfl;
-		if (nfl) {
-			const uint32_t w0 = l.written[b];
-			// the ring's read position: write position minus content, before this round's additions
-			// are accounted for -- both halves of pt grew by the same amount, so their difference is it
-			const uint32_t hc = (((w >> 16) - occ) & ring) >> 5;
-			const uint32_t o0 = ((bin0 + b) * o.regions + region) * o.cap;
-			for (uint32_t c = 0; c < nfl; ++c) {
-				l.flist[base + c] = (uint16_t)(b | (((hc + c) & (ring >> 5)) << 10));
-				l.fout[base + c] = w0 + c < o.cap ? o0 + w0 + c : 0xffffffffu;
-			}
-			l.written[b] = w0 + nfl;
+		const uint32_t slice = (tid >> 6) * (2u << l.sc_shift);
+		for (uint32_t c = 0; c < nfl; ++c) {
+			const uint32_t j = slice + incl - nfl + c;
+			l.flist[j] = (uint16_t)(b | (((hc + c) & (ring >> 5)) << 10));
+			l.fout[j] = w0 + c < o.cap ? o0 + w0 + c : 0xffffffffu;
 		}
-	}
-	__syncthreads();
-	STAMP(5);
-	// flush full chunks: 8 lanes per chunk, 16 bytes per lane -> one aligned 128-byte line
-	{
-		const uint32_t n = *l.fcount;
-		const uint32_t l8 = tid & 7;
-		for (uint32_t j = tid >> 3; j < n; j += NT / 8) {
-			const uint32_t it = l.flist[j], oc = l.fout[j];
-			const uint32_t b = it & 1023, rc = it >> 10;
-			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(b << l.sc_shift) + (rc << 5) + l8 * 4]);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// 8 lanes per chunk, 16 bytes per lane -> one aligned 128-byte line per chunk
+		const uint32_t l8 = lane & 7;
+		for (uint32_t j = lane >> 3; j < total; j += 8) {
+			const uint32_t it = l.flist[slice + j], oc = l.fout[slice + j];
+			const uint32_t fb = it & 1023, rc = it >> 10;
+			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(fb << l.sc_shift) + (rc << 5) + l8 * 4]);
 			if (oc != 0xffffffffu) {
 				*reinterpret_cast<uint4*>(&o.ent[(uint64_t)oc * kChunk + l8 * 4]) = v;
 			} else {
-				ovf(b, v.x);
-				ovf(b, v.y);
-				ovf(b, v.z);
-				ovf(b, v.w);
+				ovf(fb, v.x);
+				ovf(fb, v.y);
+				ovf(fb, v.z);
+				ovf(fb, v.w);
 			}
 		}
 	}
@@ -228,19 +230,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 			}
 		}
 	}
-	__syncthreads();
 	STAMP(7);
-	for (uint32_t b = tid; b < P; b += NT) {
-		const uint32_t w = l.pt[b], f = l.fl[b];
-		const uint32_t tot = (w & 0xffffu) - f;    // wants to be in the ring after the flush
-		const uint32_t nocc = tot < SC ? tot : SC; // entries beyond took the overflow path ...
-		const uint32_t wpos = (w >> 16) - (tot - nocc); // ... and give their ring slots back
-		l.pt[b] = (wpos << 16) | nocc;
-	}
-	if (tid == 0)
-		*l.fcount = 0;
-	STAMP(8);
-	// the caller's next barrier orders these writes before the next round
 }
 
 // flush whatever is staged and publish the ENTRY count of this workgroup's region of every bin
@@ -442,7 +432,6 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 				nxt[v] = i < n_vec ? src[i] : make_uint4(0, 0, 0, 0);
 			}
 			part_round<kPartThreads, kVec * 4>(pl, out, bin0, g, bin, val, ovf STAMP_PASS);
-			__syncthreads();
 		}
 	}
 	part_finish<kPartThreads>(pl, out, bin0, g, ovf);
