@@ -113,7 +113,7 @@ def cpu_baseline(n_reads, log2_bits):
 
 # algorithmic HBM bytes one launch of each kernel moves: per k-mer figures with
 # h = 4, L = 150, k = 31, plus the per-launch sweep of the filter array for pass C
-def kernel_bytes(slot, kmers_per_launch, filter_bytes):
+def kernel_bytes(slot, kmers_per_launch, filter_bytes, sweep_frac=1.0):
     seq = READ_LEN / (READ_LEN - K + 1)  # bytes of read buffer per k-mer
     per_kmer = {
         "insert_direct": BYTES_INSERT,        # h*128 + seq
@@ -126,8 +126,10 @@ def kernel_bytes(slot, kmers_per_launch, filter_bytes):
         "query_test": 4 * H,
         "query_resolve": 0.0,
     }.get(slot, 0.0)
+    # pass C reads (and, inserting, writes back) each filter segment once per batch; a batch is applied
+    # in several launches (groups of segments), each sweeping sweep_frac of the filter
     sweep = {"insert_apply": 2.0 * filter_bytes, "query_test": 1.0 * filter_bytes}.get(slot, 0.0)
-    return per_kmer * kmers_per_launch + sweep
+    return per_kmer * kmers_per_launch + sweep * sweep_frac
 
 
 KERNEL_NAMES = {
@@ -152,6 +154,14 @@ def load_traffic():
         except ValueError:
             return None
     return None
+
+
+def traffic_for(traffic, slot, kmers_per_launch):
+    """measured HBM bytes per launch, only when the PMC run used the same launch size as this run"""
+    t = traffic.get(slot)
+    if not t or abs(t.get("kmers_per_launch", 0) - kmers_per_launch) > 0.01 * kmers_per_launch:
+        return None
+    return t.get("bytes_per_launch")
 
 
 def main():
@@ -298,14 +308,15 @@ def main():
                 if slot == "other" or calls == 0:
                     continue
                 per_launch = kmers * args.steps / calls  # k-mers one launch processes
-                nbytes = kernel_bytes(slot, per_launch, filter_bytes)
+                batches = prof.get(slot.split("_")[0] + "_hash", (0, 0))[1]  # one pass-A launch per batch
+                nbytes = kernel_bytes(slot, per_launch, filter_bytes, batches / calls if batches else 1.0)
                 avg_s = ms / calls * 1e-3
                 kernels[slot] = {"kernel": KERNEL_NAMES.get(slot, slot), "launches": calls, "avg_launch_ms": ms / calls,
                                  "share_of_timed_region": ms * 1e-3 / elapsed, "kmers_per_launch": per_launch,
                                  "bytes_per_launch": nbytes, "achieved": nbytes / avg_s / 1e9 if avg_s else None,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS if avg_s else None,
-                                 "traffic": traffic.get(slot + "_bytes_per_launch")}
+                                 "traffic": traffic_for(traffic, slot, per_launch)}
             dom = max(kernels, key=lambda s_: kernels[s_]["share_of_timed_region"])
             d = kernels[dom]
             out["roofline"] = {"kernel": d["kernel"], "bound": "hbm", "achieved": d["achieved"], "peak": HBM_PEAK_GBS,

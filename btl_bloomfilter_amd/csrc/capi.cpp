@@ -980,16 +980,18 @@ struct PartLevel {
 	uint32_t regions = 0; // writers per bin
 	uint32_t cap = 0;     // chunks per region
 	uint32_t shift = 0;   // log2(positions per bin)
+	uint32_t alloc_bins = 0; // bins the arrays hold at a time (== bins unless the level is processed in groups)
 	uint64_t cnt_bytes = 0, ent_bytes = 0;
 	uint32_t* cnt = nullptr;
 	uint32_t* ent = nullptr;
 	PartOut out() const { return PartOut{P, regions, cap, cnt, ent}; }
-	PartIn in() const { return PartIn{1, bins, regions, cap, cnt, ent}; }
+	PartIn in() const { return PartIn{1, alloc_bins, regions, cap, cnt, ent}; }
 };
 
 struct PartPlan {
 	uint32_t seg_shift = 19;
 	uint64_t n_seg = 0;
+	uint32_t group_bins = 0; // level-0 bins split + applied together (one-split plans); 0 = all at once
 	int n_levels = 0; // lv[0] = pass A output (or the exchanged data), lv[1..] = split outputs
 	PartLevel lv[3];
 	uint64_t tiles_per_batch = 0;
@@ -1042,6 +1044,14 @@ bool plan_splits(PartPlan& pl, uint32_t regions_in_total)
 		regions_in = o.regions;
 		++pl.n_levels;
 	}
+	// a single split level is run in groups of level-0 bins (split a group, apply its segments, next
+	// group): the level-1 arrays then hold one group instead of the whole batch, so a batch can be
+	// almost twice as large for the same scratch and the filter is swept fewer times
+	pl.group_bins = 0;
+	if (pl.n_levels == 2 && pl.lv[0].bins >= 64) {
+		pl.group_bins = (pl.lv[0].bins + 7) / 8;
+		pl.lv[1].regions = std::max(1u, std::min(regions_in_total, (512 + pl.group_bins - 1) / pl.group_bins));
+	}
 	return true;
 }
 
@@ -1054,8 +1064,9 @@ void plan_caps(PartPlan& pl, double entries, int first_level)
 		// the last level has n_seg useful bins although bins may be rounded up
 		const double useful = j == pl.n_levels - 1 ? (double)std::min<uint64_t>(pl.n_seg, l.bins) : (double)l.bins;
 		l.cap = chunks_for(entries / (useful * l.regions), 1);
-		l.cnt_bytes = ((uint64_t)l.bins * l.regions * 4 + 255) / 256 * 256;
-		l.ent_bytes = (uint64_t)l.bins * l.regions * l.cap * 128;
+		l.alloc_bins = j == 1 && pl.group_bins ? pl.group_bins * l.P : l.bins;
+		l.cnt_bytes = ((uint64_t)l.alloc_bins * l.regions * 4 + 255) / 256 * 256;
+		l.ent_bytes = (uint64_t)l.alloc_bins * l.regions * l.cap * 128;
 		pl.bytes_total += l.cnt_bytes + l.ent_bytes;
 	}
 }
@@ -1119,17 +1130,37 @@ double probes_per_tile(const btlbf_filter* f, const LayoutParams& lay)
 // run the split levels lv[1..] over the level-0 data `in0`, then the apply / test pass
 int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, int query, hipStream_t s)
 {
+	const int prof_split = query ? BTLBF_PROF_QUERY_SPLIT : BTLBF_PROF_INSERT_SPLIT;
+	const int prof_apply = query ? BTLBF_PROF_QUERY_TEST : BTLBF_PROF_INSERT_APPLY;
+	if (pl.n_levels == 2 && pl.group_bins) {
+		// one split level, processed group by group
+		const PartLevel& l1 = pl.lv[1];
+		for (uint32_t b0 = 0; b0 < pl.lv[0].bins; b0 += pl.group_bins) {
+			const uint32_t nb = std::min(pl.group_bins, pl.lv[0].bins - b0);
+			{
+				ProfSpan ps(f, prof_split, s);
+				HIP_TRY(launch_part_split(f->d_data, in0, b0, nb, l1.out(), l1.shift, pl.lv[0].shift, sd, query, s));
+			}
+			const uint64_t seg_first = (uint64_t)b0 * l1.P;
+			if (seg_first >= pl.n_seg)
+				break;
+			const uint64_t n_seg = std::min<uint64_t>((uint64_t)nb * l1.P, pl.n_seg - seg_first);
+			ProfSpan ps(f, prof_apply, s);
+			HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.seg_shift, seg_first, n_seg, l1.in(), sd, query, s));
+		}
+		return BTLBF_OK;
+	}
 	PartIn in = in0;
 	uint32_t bins_in = pl.lv[0].bins, in_shift = pl.lv[0].shift;
 	for (int j = 1; j < pl.n_levels; ++j) {
-		ProfSpan ps(f, query ? BTLBF_PROF_QUERY_SPLIT : BTLBF_PROF_INSERT_SPLIT, s);
-		HIP_TRY(launch_part_split(f->d_data, in, bins_in, pl.lv[j].out(), pl.lv[j].shift, in_shift, sd, query, s));
+		ProfSpan ps(f, prof_split, s);
+		HIP_TRY(launch_part_split(f->d_data, in, 0, bins_in, pl.lv[j].out(), pl.lv[j].shift, in_shift, sd, query, s));
 		in = pl.lv[j].in();
 		bins_in = pl.lv[j].bins;
 		in_shift = pl.lv[j].shift;
 	}
-	ProfSpan ps(f, query ? BTLBF_PROF_QUERY_TEST : BTLBF_PROF_INSERT_APPLY, s);
-	HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.seg_shift, pl.n_seg, in, sd, query, s));
+	ProfSpan ps(f, prof_apply, s);
+	HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.seg_shift, 0, pl.n_seg, in, sd, query, s));
 	return BTLBF_OK;
 }
 
@@ -1169,6 +1200,7 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, Par
 		l0.bins = (uint32_t)((pl.n_seg + (1ull << b1) - 1) >> b1);
 	}
 	l0.P = l0.bins;
+	l0.alloc_bins = l0.bins;
 	l0.regions = cu_count(f->device); // one pass-A workgroup per CU (LDS-bound)
 	if (!plan_splits(pl, l0.regions) || !part_hash_fits(f->hp, l0.P))
 		return BTLBF_OK;

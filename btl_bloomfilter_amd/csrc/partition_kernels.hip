@@ -382,14 +382,18 @@ __device__ __forceinline__ uint32_t part_in_region(const PartIn& in, uint32_t b,
 // workgroup (b, g): blockIdx.x = b * slices + g.  It consumes input regions g, g+slices, ... of input
 // bin b and writes region g of every sub-bin b*P + sub, sub = entry >> sub_shift; the new entry is
 // the low sub_shift bits.  in_shift = log2(positions per input bin), for the overflow path.
+// Only input bins [first_bin, first_bin + gridDim.x/slices) are processed (a GROUP of bins: the output
+// arrays hold one group at a time, which keeps the level-1 scratch small); output bins are numbered
+// relative to the group.
 template <bool QUERY>
 __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, const PartIn in, const PartOut out,
                                                                  const uint32_t slices, const uint32_t sub_shift,
-                                                                 const uint32_t in_shift, const PartSide sd)
+                                                                 const uint32_t in_shift, const uint32_t first_bin,
+                                                                 const PartSide sd)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	const uint32_t tid = threadIdx.x;
-	const uint32_t b = blockIdx.x / slices, g = blockIdx.x % slices;
+	const uint32_t b = first_bin + blockIdx.x / slices, g = blockIdx.x % slices;
 	const PartLds pl = part_carve(dyn, out.P);
 	part_init<kPartThreads>(pl, out.P);
 	uint32_t* words = static_cast<uint32_t*>(filter);
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 	auto ovf = [&](uint32_t sub, uint32_t v) {
 		part_direct<QUERY>(words, sd, bin_base | ((uint64_t)sub << sub_shift) | v);
 	};
-	const uint32_t bin0 = b * out.P;
+	const uint32_t bin0 = (b - first_bin) * out.P;
 	const uint32_t n_regions_in = in.blocks * in.regions_per_block;
 	constexpr int kVec = 4; // uint4 loads per thread per round -> 16 entries
 	STAMP_DECL;
@@ -440,22 +444,24 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 // ---- pass C --------------------------------------------------------------------------------------
 // one workgroup per segment (= input bin `seg`); pos_base + (seg << seg_shift | entry) is the
 // position reported for failed tests
+// Input bin blockIdx.x holds the entries of segment seg_first + blockIdx.x (group-relative numbering).
 template <bool QUERY>
 __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
-                                                                 uint32_t seg_shift, const PartIn in,
-                                                                 const PartSide sd)
+                                                                 uint32_t seg_shift, uint32_t seg_first,
+                                                                 const PartIn in, const PartSide sd)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	__shared__ uint32_t any;
 	const uint32_t tid = threadIdx.x;
-	const uint32_t seg = blockIdx.x;
+	const uint32_t ibin = blockIdx.x;
+	const uint32_t seg = seg_first + blockIdx.x;
 	const uint32_t n_regions = in.blocks * in.regions_per_block;
 	if (tid == 0)
 		any = 0;
 	__syncthreads();
 	uint32_t mine = 0;
 	for (uint32_t r = tid; r < n_regions; r += kApplyThreads)
-		mine |= in.cnt[part_in_region(in, seg, r)];
+		mine |= in.cnt[part_in_region(in, ibin, r)];
 	if (mine)
 		any = 1;
 	__syncthreads();
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 	__syncthreads();
 	uint32_t* lds = reinterpret_cast<uint32_t*>(dyn);
 	for (uint32_t r = 0; r < n_regions; ++r) {
-		const uint32_t reg = part_in_region(in, seg, r);
+		const uint32_t reg = part_in_region(in, ibin, r);
 		uint32_t n = in.cnt[reg];
 		if (n > in.cap * kChunk)
 			n = in.cap * kChunk;
@@ -592,9 +598,11 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bi
 	             : launch_hash_q<false>(a, out, bin_shift, sd, dyn, s);
 }
 
-hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t n_in_bins, const PartOut& out,
+hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_bin, uint32_t n_in_bins, const PartOut& out,
                              uint32_t sub_shift, uint32_t in_shift, const PartSide& sd, int query, hipStream_t s)
 {
+	if (n_in_bins == 0)
+		return hipSuccess;
 	const size_t dyn = part_lds_bytes(out.P);
 	const void* fn = query ? reinterpret_cast<const void*>(&part_split_kernel<true>)
 	                       : reinterpret_cast<const void*>(&part_split_kernel<false>);
@@ -605,16 +613,18 @@ hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t n_in_bins,
 	const dim3 grid(n_in_bins * slices);
 	if (query)
 		hipLaunchKernelGGL(part_split_kernel<true>, grid, dim3(kPartThreads), dyn, s, filter, in, out, slices,
-		                   sub_shift, in_shift, sd);
+		                   sub_shift, in_shift, first_bin, sd);
 	else
 		hipLaunchKernelGGL(part_split_kernel<false>, grid, dim3(kPartThreads), dyn, s, filter, in, out, slices,
-		                   sub_shift, in_shift, sd);
+		                   sub_shift, in_shift, first_bin, sd);
 	return hipGetLastError();
 }
 
-hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_shift, uint64_t n_seg, const PartIn& in,
-                             const PartSide& sd, int query, hipStream_t s)
+hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_shift, uint64_t seg_first, uint64_t n_seg,
+                             const PartIn& in, const PartSide& sd, int query, hipStream_t s)
 {
+	if (n_seg == 0)
+		return hipSuccess;
 	const size_t dyn = (size_t)1 << (seg_shift - 3);
 	const void* fn = query ? reinterpret_cast<const void*>(&part_apply_kernel<true>)
 	                       : reinterpret_cast<const void*>(&part_apply_kernel<false>);
@@ -623,10 +633,10 @@ hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_sh
 		return e;
 	if (query)
 		hipLaunchKernelGGL(part_apply_kernel<true>, dim3((unsigned)n_seg), dim3(kApplyThreads), dyn, s,
-		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, in, sd);
+		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, (uint32_t)seg_first, in, sd);
 	else
 		hipLaunchKernelGGL(part_apply_kernel<false>, dim3((unsigned)n_seg), dim3(kApplyThreads), dyn, s,
-		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, in, sd);
+		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, (uint32_t)seg_first, in, sd);
 	return hipGetLastError();
 }
 
