@@ -29,8 +29,9 @@ namespace btlbf {
 // 1024-thread workgroups (4 waves per SIMD; one workgroup per CU because the staging rings fill the
 // LDS) with 4 windows per lane in pass A and 16 entries per lane in pass B: <= 128 VGPRs
 static constexpr int kPartThreads = 1024;
-static constexpr int kPartW = 4;                        // windows per lane in pass A
-static constexpr int kPartTile = kPartThreads * kPartW; // windows per round of pass A
+static constexpr int kPartW = 8;                        // windows per lane and tile in pass A ...
+static constexpr int kPartHalf = 4;                     // ... partitioned in two rounds of 4 (the rings hold one)
+static constexpr int kPartTile = kPartThreads * kPartW; // windows per tile of pass A
 static constexpr int kApplyThreads = 512;
 static constexpr uint32_t kChunk = 32;           // entries per chunk
 static constexpr uint32_t kNoBin = 0xffffffffu;  // empty entry slot of a lane (registers only)
@@ -331,36 +332,40 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
 		STAMP(1);
 
-		uint32_t bin[kPartW * H], val[kPartW * H];
+		// the lane hashes its 8 consecutive windows with ONE start-up; after every 4 windows the
+		// 4*H entries collected so far go through a partition round (the rolling state stays in
+		// registers across it)
+		uint32_t bin[kPartHalf * H], val[kPartHalf * H];
 		uint32_t vmask = 0;
 		seq_lane_windows<SPACED, kPartW>(tile, sh, a.hp, spaced_lds, tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
 			vmask |= (uint32_t)ok << w;
+			const int w4 = w % kPartHalf;
 #pragma unroll
 			for (int i = 0; i < H; ++i) {
 				// positions outside this GPU's window (a shard) are dropped; without sharding the
 				// window is the whole filter and the test is always true
 				const uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod) - a.mod.shard_lo;
 				const bool mine = ok && p < a.mod.shard_len;
-				bin[w * H + i] = mine ? (uint32_t)(p >> bin_shift) : kNoBin;
-				val[w * H + i] = (uint32_t)p & ent_mask;
+				bin[w4 * H + i] = mine ? (uint32_t)(p >> bin_shift) : kNoBin;
+				val[w4 * H + i] = (uint32_t)p & ent_mask;
+			}
+			if (w4 == kPartHalf - 1) {
+				STAMP(2);
+				part_round<kPartThreads, kPartHalf * H>(pl, out, 0, blockIdx.x, bin, val, ovf STAMP_PASS);
 			}
 		});
 		if (a.valid_bits || a.hit_bits) {
-			// two lanes (4 windows each) make one byte of the per-window bitmaps
-			static_assert(kPartW == 4, "nibble packing");
-			const uint32_t other = __shfl_xor(vmask, 1, 64);
-			const uint64_t ob = (g0 >> 3) + (tid >> 1);
-			if (!(tid & 1) && ob < out_bytes) {
-				const uint8_t v = (uint8_t)(vmask | (other << 4));
+			// one byte of the per-window bitmaps per lane
+			static_assert(kPartW == 8, "one bitmap byte per lane");
+			const uint64_t ob = (g0 >> 3) + tid;
+			if (ob < out_bytes) {
 				if (a.valid_bits)
-					a.valid_bits[ob] = v;
+					a.valid_bits[ob] = (uint8_t)vmask;
 				if (a.hit_bits)
-					a.hit_bits[ob] = v; // a query starts from "every clean window hits"
+					a.hit_bits[ob] = (uint8_t)vmask; // a query starts from "every clean window hits"
 			}
 		}
 		my_valid += __popc(vmask);
-		STAMP(2);
-		part_round<kPartThreads, kPartW * H>(pl, out, 0, blockIdx.x, bin, val, ovf STAMP_PASS);
 	}
 	part_finish<kPartThreads>(pl, out, 0, blockIdx.x, ovf);
 	if (a.counts) {
