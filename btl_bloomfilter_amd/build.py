@@ -1,36 +1,70 @@
-"""Build the HIP shared library in-tree:  python -m btl_bloomfilter_amd.build
+"""Build the HIP shared library in-tree:  python -m btl_bloomfilter_amd.build [--force]
 
-hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels to the GPU box
-with the repo snapshot."""
+hipcc cross-compiles for gfx950 without a GPU.  Translation units are compiled in parallel into
+btl_bloomfilter_amd/_build/ and linked into libbtlbf.so; the .so is git-ignored but travels to the GPU
+box with the repo snapshot (the objects do not: .gpurunignore)."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libbtlbf.so")
-SOURCES = ["capi.cpp", "seq_kernels.hip", "aux_kernels.hip", "partition_kernels.hip"]
-HEADERS = ["internal.hpp", "device_utils.hpp", "seq_core.hpp", os.path.join("..", "..", "include", "btlbf.h")]
+HEADERS = ["internal.hpp", "device_utils.hpp", "seq_core.hpp", "partition_core.hpp",
+           os.path.join("..", "..", "include", "btlbf.h")]
+# (object name, source, extra flags): pass A of the partitioned pipeline is one unit per hash count
+UNITS = [("capi", "capi.cpp", []), ("seq_kernels", "seq_kernels.hip", []), ("aux_kernels", "aux_kernels.hip", []),
+         ("partition_kernels", "partition_kernels.hip", [])]
+UNITS += [("part_hash_h%d" % h, "part_hash_inst.hip", ["-DBTLBF_PART_H=%d" % h]) for h in range(1, 9)]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newest_header():
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + ["../build.py"])
+
+
+def _extra_flags():
+    return os.environ.get("BTLBF_CXXFLAGS", "").split()
 
 
 def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return _newest_header() > t or any(os.path.getmtime(os.path.join(CSRC, src)) > t for _, src, _ in UNITS)
 
 
-def build(force=False, verbose=False):
+def _compile(unit, hipcc, force, verbose):
+    name, src, extra = unit
+    obj = os.path.join(OBJ, name + ".o")
+    srcp = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _newest_header()):
+        return obj
+    cmd = [hipcc] + FLAGS + _extra_flags() + extra + ["-c", "-o", obj, srcp]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, r.stdout, r.stderr))
+    return obj
+
+
+def build(force=False, verbose=False, jobs=None):
     if not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda u: _compile(u, hipcc, force, verbose), UNITS))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     return LIB
 
 

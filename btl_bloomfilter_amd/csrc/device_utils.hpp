@@ -11,7 +11,8 @@ __device__ __forceinline__ uint64_t srol1(uint64_t x)
 {
 	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
 	const uint32_t nlo = (lo << 1) | (hi & 1u);
-	const uint32_t nhi = ((hi << 1) & 0xfffffffcu) | ((hi >> 30) & 2u) | (lo >> 31);
+	const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 31); // hi<<1 | lo>>31: all but bit 1 are right
+	const uint32_t nhi = (t & ~2u) | ((hi >> 30) & 2u);       // v_bfi
 	return ((uint64_t)nhi << 32) | nlo;
 }
 
@@ -20,8 +21,9 @@ __device__ __forceinline__ uint64_t srol1(uint64_t x)
 __device__ __forceinline__ uint64_t sror1(uint64_t x)
 {
 	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-	const uint32_t nlo = (lo >> 1) | (hi << 31);
-	const uint32_t nhi = ((hi >> 1) & 0x7ffffffeu) | ((hi & 2u) << 30) | (lo & 1u);
+	const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, 1); // lo>>1 | hi<<31
+	const uint32_t t = ((hi >> 1) & ~1u) | (lo & 1u);          // v_bfi
+	const uint32_t nhi = (t & 0x7fffffffu) | ((hi << 30) & 0x80000000u);
 	return ((uint64_t)nhi << 32) | nlo;
 }
 

@@ -18,11 +18,14 @@ static constexpr unsigned kMultiShift = 27;
 // 4..7 are the raw bytes {4,5} 7 3 1 that the reference's seedTab also accepts
 // (vendor/nthash.hpp:196): their forward seed is A C G T and -- because "c & cpOff" maps such a
 // byte to itself (nthash.hpp:180,688) -- their reverse-strand seed is the SAME seed.
-// per-base byte staged in LDS: bits 2:0 code, bit 3 = valid base, bit 4 = first base of a sequence
-static constexpr unsigned kCodeMask = 7u;
+// per-base byte staged in LDS: bits 6:4 code (byte & kCodeOff is the byte offset of a 16-byte table
+// entry), bit 0 = valid base, bit 1 = valid base that is not the first of a sequence (a window is
+// clean when its first base is valid and the k-1 bases after it are all "good" in this sense)
+static constexpr unsigned kCodeShift = 4u;
+static constexpr unsigned kCodeOff = 0x70u;
 static constexpr unsigned kNumCodes = 8u;
-static constexpr unsigned kBaseValid = 8u;
-static constexpr unsigned kBaseStart = 16u;
+static constexpr unsigned kBaseValid = 1u;
+static constexpr unsigned kBaseGood = 2u;
 
 static constexpr int kMaxHash = 32;  // hash_num supported by the fused kernels
 static constexpr int kMaxSeeds = 16; // spaced seeds per filter

@@ -1,0 +1,295 @@
+// csrc/partition_core.hpp -- device code shared by the partition passes (partition_kernels.hip and the
+// per-hash-count instantiations of pass A in part_hash_inst.hip): LDS layout of the staged
+// partitioner, the partition round, overflow paths.  See partition_kernels.hip for the overview.
+#pragma once
+#include "seq_core.hpp"
+
+namespace btlbf {
+
+// 1024-thread workgroups (4 waves per SIMD; one workgroup per CU because the staging rings fill the
+// LDS) with 4 windows per lane in pass A and 16 entries per lane in pass B: <= 128 VGPRs
+static constexpr int kPartThreads = 1024;
+static constexpr int kPartW = 8;                        // windows per lane and tile in pass A ...
+static constexpr int kPartHalf = 4;                     // ... partitioned in two rounds of 4 (the rings hold one)
+static constexpr int kPartTile = kPartThreads * kPartW; // windows per tile of pass A
+static constexpr int kApplyThreads = 512;
+static constexpr uint32_t kChunk = 32;           // entries per chunk
+static constexpr uint32_t kStageEntries = 32768; // LDS staging: 128 KiB of uint32 entries
+static constexpr uint32_t kPartLdsBudget = 160 * 1024 - 1536; // dynamic LDS a workgroup may ask for (static: SeqShared)
+
+// LDS image of the staged partitioner (carved from dynamic LDS by the kernels)
+struct PartLds {
+	uint32_t* stage;   // [P][SC] ring per bin, SC = kStageEntries / pow2ceil(P)
+	uint32_t* pt;      // [P] low 16 bits: entries in the ring (+ offered this round); high 16: ring write position
+	uint32_t* fl;      // [P] entries flushed from the bin this round (multiple of 32)
+	uint32_t* written; // [P] chunks written to this workgroup's region of the bin
+	uint32_t* fout;    // [1024] flush items, a private slice per wave: output chunk index ...
+	uint16_t* flist;   // [1024] ... and bin | ring chunk << 10
+	uint32_t sc_shift; // log2(SC)
+};
+
+__host__ __device__ inline uint32_t part_pow2ceil(uint32_t x)
+{
+	uint32_t p = 1;
+	while (p < x)
+		p <<= 1;
+	return p;
+}
+
+__host__ __device__ inline uint32_t part_lds_bytes(uint32_t P)
+{
+	return kStageEntries * 4 + 3 * P * 4 + 1024 * 4 + 1024 * 2 + 16;
+}
+
+__device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
+{
+	PartLds l;
+	l.stage = reinterpret_cast<uint32_t*>(base);
+	l.pt = l.stage + kStageEntries;
+	l.fl = l.pt + P;
+	l.written = l.fl + P;
+	l.fout = l.written + P;
+	l.flist = reinterpret_cast<uint16_t*>(l.fout + 1024);
+	uint32_t pc = part_pow2ceil(P < 32 ? 32 : P), sh = 0;
+	while ((kStageEntries >> sh) > pc)
+		++sh; // kStageEntries / 2^sh == pc  ->  SC = 2^sh
+	l.sc_shift = sh;
+	return l;
+}
+
+template <int NT>
+__device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
+{
+	for (uint32_t b = threadIdx.x; b < P; b += NT) {
+		l.pt[b] = 0;
+		l.fl[b] = 0;
+		l.written[b] = 0;
+	}
+}
+
+#ifdef BTLBF_PHASE_STAMPS
+#define STAMP(i)                                               \
+	do {                                                       \
+		if (threadIdx.x == 0) {                                \
+			const uint64_t t__ = __builtin_readcyclecounter(); \
+			g_stamp[i] += t__ - g_last;                        \
+			g_last = t__;                                      \
+		}                                                      \
+	} while (0)
+static __device__ uint64_t g_stamp_out[16];
+#define STAMP_DECL uint64_t g_stamp[16] = {0}, g_last = __builtin_readcyclecounter()
+#define STAMP_FLUSH                                                                                  \
+	do {                                                                                             \
+		if (threadIdx.x == 0)                                                                        \
+			for (int i__ = 0; i__ < 16; ++i__)                                                       \
+				atomicAdd((unsigned long long*)&g_stamp_out[i__], (unsigned long long)g_stamp[i__]); \
+	} while (0)
+#define STAMP_ARGS , uint64_t (&g_stamp)[16], uint64_t& g_last
+#define STAMP_PASS , g_stamp, g_last
+#else
+#define STAMP(i)
+#define STAMP_DECL
+#define STAMP_FLUSH
+#define STAMP_ARGS
+#define STAMP_PASS
+#endif
+
+// One round: every thread contributes up to E entries (in groups of G, see `live`) to the bins
+// [0, o.P) of this workgroup's output block; block-local bin b is global bin bin0 + b.
+// Region `region` of global bin g is chunks [(g*o.regions + region)*o.cap, +o.cap) of o.ent
+// (32-bit chunk indices: a pass's output holds fewer than 2^32 chunks).
+// `ovf(bin, val)` takes the entries that cannot be staged.
+//
+// pt[b] packs (ring write position << 16 | entries in the ring).  Three phases, two barriers:
+//  1. ONE returning LDS atomic per entry adds 0x10001: the old value is the entry's ring slot (high
+//     half) and how many entries are ahead of it (low half; fewer than SC means it fits and is written
+//     now; otherwise it is "late").
+//  2. the lane that owns bin b (b = lane index) sees how much arrived, copies the bin's full 32-entry
+//     chunks from the ring to this workgroup's region (one aligned 128-byte line each) and already
+//     writes the bin's state for the next round: what the late entries will do is determined by
+//     their old values alone (those still beyond the ring after the flush overflow and give their
+//     slots back), so nothing has to wait for them.
+//  3. late entries move into the ring space the flush freed, or overflow.
+// No barrier is needed after phase 3: the next round's phase 1 only touches pt (final since phase 2)
+// and ring slots behind the late ones; its phase 2 comes after its own barrier.
+template <int NT, int E, int G, class OVF>
+__device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
+                                           const uint32_t (&bin)[E], const uint32_t (&val)[E], const uint32_t live,
+                                           OVF&& ovf STAMP_ARGS)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint32_t P = o.P;
+	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
+	uint32_t old[E];
+	uint32_t late = 0; // bit e: entry e found no room before this round's flush
+	static_assert(E <= 32 && E % G == 0, "one flag bit per entry; whole groups");
+	// bit g of `live`: the G entries of group g exist (pass A: the H probes of one clean window).
+	// All atomics of the lane are issued back to back (independent), then consumed.
+#pragma unroll
+	for (int g = 0; g < E / G; ++g) {
+		if ((live >> g) & 1) {
+#pragma unroll
+			for (int e = g * G; e < (g + 1) * G; ++e)
+				old[e] = atomicAdd(&l.pt[bin[e]], 0x10001u);
+		}
+	}
+#pragma unroll
+	for (int g = 0; g < E / G; ++g) {
+		if ((live >> g) & 1) {
+#pragma unroll
+			for (int e = g * G; e < (g + 1) * G; ++e) {
+				if ((old[e] & 0xffffu) < SC)
+					l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 16) & ring)] = val[e];
+				else
+					late |= 1u << e;
+			}
+		}
+	}
+	__syncthreads();
+	STAMP(4);
+	{
+		// bins are owned by lanes (P <= NT): wave v owns bins [64v, 64v+64) and flushes them itself,
+		// through its private slice of the flush list -- no workgroup barrier in between
+		const uint32_t b = tid, lane = tid & 63;
+		uint32_t nfl = 0, hc = 0, o0 = 0, w0 = 0;
+		if (b < P) {
+			const uint32_t w = l.pt[b];
+			const uint32_t occ = w & 0xffffu;           // ring content + everything offered this round
+			const uint32_t avail = occ < SC ? occ : SC; // entries that really sit in the ring
+			nfl = avail >> 5;
+			const uint32_t f = nfl << 5;
+			// state for the next round (see above)
+			const uint32_t tot = occ - f;
+			const uint32_t nocc = tot < SC ? tot : SC;
+			l.pt[b] = (((w >> 16) - (tot - nocc)) << 16) | nocc;
+			l.fl[b] = f;
+			if (nfl) {
+				w0 = l.written[b];
+				l.written[b] = w0 + nfl;
+				// read position of the ring: both halves of pt grew by the same amount this round
+				hc = (((w >> 16) - occ) & ring) >> 5;
+				o0 = ((bin0 + b) * o.regions + region) * o.cap;
+			}
+		}
+		// exclusive prefix sum of nfl over the wave -> slots in the wave's slice (2*SC items)
+		uint32_t incl = nfl;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(incl, d, 64);
+			if (lane >= (uint32_t)d)
+				incl += t;
+		}
+		const uint32_t total = __shfl(incl, 63, 64);
+		const uint32_t slice = (tid >> 6) * (2u << l.sc_shift);
+		for (uint32_t c = 0; c < nfl; ++c) {
+			const uint32_t j = slice + incl - nfl + c;
+			l.flist[j] = (uint16_t)(b | (((hc + c) & (ring >> 5)) << 10));
+			l.fout[j] = w0 + c < o.cap ? o0 + w0 + c : 0xffffffffu;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// 8 lanes per chunk, 16 bytes per lane -> one aligned 128-byte line per chunk
+		const uint32_t l8 = lane & 7;
+		for (uint32_t j = lane >> 3; j < total; j += 8) {
+			const uint32_t it = l.flist[slice + j], oc = l.fout[slice + j];
+			const uint32_t fb = it & 1023, rc = it >> 10;
+			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(fb << l.sc_shift) + (rc << 5) + l8 * 4]);
+			if (oc != 0xffffffffu) {
+				*reinterpret_cast<uint4*>(&o.ent[(uint64_t)oc * kChunk + l8 * 4]) = v;
+			} else {
+				ovf(fb, v.x);
+				ovf(fb, v.y);
+				ovf(fb, v.z);
+				ovf(fb, v.w);
+			}
+		}
+	}
+	__syncthreads();
+	STAMP(6);
+	// entries that did not fit before the flush: into the freed ring space, else overflow
+	if (late) {
+#pragma unroll
+		for (int e = 0; e < E; ++e) {
+			if ((late >> e) & 1) {
+				if ((old[e] & 0xffffu) - l.fl[bin[e]] < SC)
+					l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 16) & ring)] = val[e];
+				else
+					ovf(bin[e], val[e]);
+			}
+		}
+	}
+	STAMP(7);
+}
+
+// flush whatever is staged and publish the ENTRY count of this workgroup's region of every bin
+template <int NT, class OVF>
+__device__ __forceinline__ void part_finish(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
+                                            OVF&& ovf)
+{
+	__syncthreads();
+	const uint32_t tid = threadIdx.x, lane32 = tid & 31;
+	const uint32_t ring = (1u << l.sc_shift) - 1;
+	for (uint32_t b = tid >> 5; b < o.P; b += NT / 32) {
+		const uint32_t w = l.pt[b], n = w & 0xffffu, hd = ((w >> 16) - n) & ring;
+		const uint32_t w0 = l.written[b];
+		const uint32_t full = w0 < o.cap ? w0 : o.cap; // chunks of this region that really hold data
+		const uint32_t o0 = ((bin0 + b) * o.regions + region) * o.cap;
+		uint32_t stored = 0;
+		for (uint32_t c = 0; c * kChunk < n; ++c) {
+			const uint32_t i = c * kChunk + lane32;
+			const uint32_t v = i < n ? l.stage[(b << l.sc_shift) + ((hd + i) & ring)] : 0;
+			if (w0 + c < o.cap) {
+				o.ent[(uint64_t)(o0 + w0 + c) * kChunk + lane32] = v;
+				stored = (c + 1) * kChunk < n ? (c + 1) * kChunk : n;
+			} else if (i < n) {
+				ovf(b, v);
+			}
+		}
+		if (lane32 == 0)
+			o.cnt[(bin0 + b) * o.regions + region] = full * kChunk + stored;
+	}
+}
+
+// where the overflow entries of the routing passes go (multi-GPU): global positions
+__device__ __forceinline__ void part_spill(const PartSide& sd, uint64_t pos)
+{
+	const unsigned long long i = atomicAdd(sd.spill_count, 1ull);
+	if (i < sd.spill_cap)
+		sd.spill_list[i] = pos;
+}
+// positions whose bit was found clear (partitioned contains)
+__device__ __forceinline__ void part_report_fail(const PartSide& sd, uint64_t pos)
+{
+	const unsigned long long i = atomicAdd(sd.fail_count, 1ull);
+	if (i < sd.fail_cap)
+		sd.fail_list[i] = pos;
+}
+// overflow of an insert / contains pass: spill list when routing, else straight to the filter
+template <bool QUERY>
+__device__ __forceinline__ void part_direct(uint32_t* words, const PartSide& sd, uint64_t lp)
+{
+	if (sd.spill_count)
+		part_spill(sd, sd.pos_base + lp);
+	else if (!QUERY)
+		bf_set(words, lp);
+	else if (!((bf_word(words, lp) >> (lp & 31)) & 1u))
+		part_report_fail(sd, sd.pos_base + lp);
+}
+
+
+// pass A launchers, one translation unit per hash count (part_hash_inst.hip, -DBTLBF_PART_H=n)
+#define BTLBF_DECL_HASH_LAUNCH(n)                                                                              \
+	hipError_t launch_part_hash_h##n(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd, \
+	                                 size_t dyn, int query, hipStream_t s);
+BTLBF_DECL_HASH_LAUNCH(1)
+BTLBF_DECL_HASH_LAUNCH(2)
+BTLBF_DECL_HASH_LAUNCH(3)
+BTLBF_DECL_HASH_LAUNCH(4)
+BTLBF_DECL_HASH_LAUNCH(5)
+BTLBF_DECL_HASH_LAUNCH(6)
+BTLBF_DECL_HASH_LAUNCH(7)
+BTLBF_DECL_HASH_LAUNCH(8)
+#undef BTLBF_DECL_HASH_LAUNCH
+
+} // namespace btlbf

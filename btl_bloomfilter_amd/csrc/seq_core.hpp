@@ -4,10 +4,11 @@
 //
 // A tile is NT*kW consecutive window start offsets (NT = workgroup size, kW = 8 windows per lane).
 //   seq_setup_tables : one-time LDS tables (byte -> base code LUT, Horner/roll seed tables, spaced-seed tables)
-//   seq_stage_tile   : coalesced 16-byte loads of the tile's bytes -> LDS byte per base
-//                      (bits 2:0 code, bit 3 valid, bit 4 first base of a sequence)
-//   seq_lane_windows : Horner start-up over the lane's first window, then kW-1 O(1) rolls; calls
-//                      f(w, clean, hashes) for each of the lane's windows
+//   seq_stage_tile   : coalesced loads of the tile's bytes -> LDS byte per base
+//                      (bits 6:4 code, bit 0 valid, bit 1 valid and not the first base of a sequence)
+//   seq_lane_windows : start-up over the lane's first window (four bases per LDS word, one 16-byte
+//                      table entry per base), then kW-1 O(1) rolls (one pair-table entry per roll);
+//                      calls f(w, clean, hashes) for each of the lane's windows
 // Reference semantics reproduced (not its code): ntHashIterator init/next
 // (vendor/ntHashIterator.hpp:59-86), NTMC64/NTMSM64 (vendor/nthash.hpp:581-590,667-692,820-878).
 #pragma once
@@ -23,9 +24,8 @@ struct __attribute__((aligned(16))) U64x2 {
 
 // static LDS shared by the sequence kernels
 struct SeqShared {
+	U64x2 pair_tab[kNumCodes * kNumCodes]; // [outgoing code * 8 + incoming code]: the roll's XOR terms for both strands
 	U64x2 init_tab[kNumCodes];
-	U64x2 in_tab[kNumCodes];
-	U64x2 out_tab[kNumCodes];
 	uint8_t lut[256];
 	unsigned long long cnt_valid;
 	unsigned long long cnt_hit;
@@ -35,15 +35,16 @@ struct SeqShared {
 // ASCII byte -> code | valid (what vendor/nthash.hpp:195-228 accepts: ACGTU acgtu and 1 3 4 5 7)
 __device__ __forceinline__ uint8_t base_entry(uint32_t c)
 {
+	constexpr uint32_t ok = kBaseValid | kBaseGood;
 	switch (c) {
-	case 'A': case 'a': return 0 | kBaseValid;
-	case 'C': case 'c': return 1 | kBaseValid;
-	case 'G': case 'g': return 2 | kBaseValid;
-	case 'T': case 't': case 'U': case 'u': return 3 | kBaseValid;
-	case 4: case 5: return 4 | kBaseValid; // raw bytes: forward A C G T, reverse seed = forward seed
-	case 7: return 5 | kBaseValid;
-	case 3: return 6 | kBaseValid;
-	case 1: return 7 | kBaseValid;
+	case 'A': case 'a': return (0 << kCodeShift) | ok;
+	case 'C': case 'c': return (1 << kCodeShift) | ok;
+	case 'G': case 'g': return (2 << kCodeShift) | ok;
+	case 'T': case 't': case 'U': case 'u': return (3 << kCodeShift) | ok;
+	case 4: case 5: return (4 << kCodeShift) | ok; // raw bytes: forward A C G T, reverse seed = forward seed
+	case 7: return (5 << kCodeShift) | ok;
+	case 3: return (6 << kCodeShift) | ok;
+	case 1: return (7 << kCodeShift) | ok;
 	default: return 0;
 	}
 }
@@ -72,10 +73,11 @@ __device__ __forceinline__ void seq_setup_tables(SeqShared& sh, const HashParams
 	const uint32_t tid = threadIdx.x;
 	for (uint32_t i = tid; i < 256; i += NT)
 		sh.lut[i] = base_entry(i);
-	if (tid < kNumCodes) {
+	if (tid < kNumCodes)
 		sh.init_tab[tid] = U64x2{hp.init_tab[tid][0], hp.init_tab[tid][1]};
-		sh.in_tab[tid] = U64x2{hp.in_tab[tid][0], hp.in_tab[tid][1]};
-		sh.out_tab[tid] = U64x2{hp.out_tab[tid][0], hp.out_tab[tid][1]};
+	for (uint32_t i = tid; i < kNumCodes * kNumCodes; i += NT) {
+		const uint32_t co = i / kNumCodes, ci = i % kNumCodes;
+		sh.pair_tab[i] = U64x2{hp.in_tab[ci][0] ^ hp.out_tab[co][0], hp.in_tab[ci][1] ^ hp.out_tab[co][1]};
 	}
 	if (tid == 0) {
 		sh.cnt_valid = 0;
@@ -153,7 +155,7 @@ __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_
 				e = 0;
 			if (uniform) {
 				if (r == 0)
-					e |= kBaseStart;
+					e &= ~kBaseGood;
 				r = (r + 1 == L) ? 0 : r + 1;
 			}
 			o |= e << (8 * b);
@@ -180,7 +182,7 @@ __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_
 			if (p >= g0 + need)
 				break;
 			const uint32_t li = (uint32_t)(p - g0) + mis;
-			atomicOr(reinterpret_cast<uint32_t*>(tile) + (li >> 2), kBaseStart << (8 * (li & 3)));
+			atomicAnd(reinterpret_cast<uint32_t*>(tile) + (li >> 2), ~(kBaseGood << (8 * (li & 3))));
 		}
 	}
 	__syncthreads();
@@ -203,62 +205,96 @@ struct WinHash {
 	}
 };
 
+// unaligned LDS reads (gfx950's DS unit takes unaligned b32/b64 addresses)
+__device__ __forceinline__ uint32_t lds_u32(const uint8_t* p)
+{
+	uint32_t v;
+	__builtin_memcpy(&v, p, 4);
+	return v;
+}
+__device__ __forceinline__ uint64_t lds_u64(const uint8_t* p)
+{
+	uint64_t v;
+	__builtin_memcpy(&v, p, 8);
+	return v;
+}
+__device__ __forceinline__ U64x2 tab16(const void* base, uint32_t byte_off)
+{
+	return *reinterpret_cast<const U64x2*>(static_cast<const uint8_t*>(base) + byte_off);
+}
+
 // Walk the lane's KW consecutive windows (first base at LDS index li0) and call
 // f(w, clean, const WinHash<SPACED>&) for each.
 template <bool SPACED, int KW = kW, class F>
 __device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqShared& sh, const HashParams& hp,
                                                  const uint8_t* spaced_lds, uint32_t li0, F&& f)
 {
+	static_assert(KW <= 8, "the lane's outgoing / incoming bases are held in one 64-bit register each");
 	const uint32_t k = hp.k;
-	const U64x2* pos_tab = reinterpret_cast<const U64x2*>(spaced_lds);
+	const uint8_t* pos_tab = spaced_lds; // 16-byte entries, entry (i, code) at byte i*128 + code*16
 	const uint16_t* dc_idx = reinterpret_cast<const uint16_t*>(spaced_lds + seq_pos_tab_bytes(hp));
-	uint64_t fh, rh;
-	uint32_t cnt = 0; // valid, non-start bases among the k-1 bases after the window's first
-	uint32_t first_valid;
+	const uint8_t* bp = tile + li0;
+	uint64_t fh = 0, rh = 0;
+	uint32_t good = 0; // "good" bases among the window's k bases (the first base's flag is taken out below)
+	uint32_t i = 0;
 	if (hp.use_pos_tab) {
-		// first window from the positional table: one 16-byte LDS read and two XORs per base
-		uint32_t e = tile[li0];
-		first_valid = (e >> 3) & 1;
-		U64x2 tt = pos_tab[e & kCodeMask];
-		fh = tt.x;
-		rh = tt.y;
-		for (uint32_t i = 1; i < k; ++i) {
-			e = tile[li0 + i];
-			tt = pos_tab[i * kNumCodes + (e & kCodeMask)];
+		// first window from the positional table: four bases per LDS word, one 16-byte entry and two
+		// 64-bit XORs per base
+		for (; i + 4 <= k; i += 4) {
+			const uint32_t w = lds_u32(bp + i);
+			good += __popc(w & (kBaseGood * 0x01010101u));
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				const U64x2 tt = tab16(pos_tab, (i + b) * (kNumCodes * 16) + ((w >> (8 * b)) & kCodeOff));
+				fh ^= tt.x;
+				rh ^= tt.y;
+			}
+		}
+		for (; i < k; ++i) {
+			const uint32_t e = bp[i];
+			good += (e / kBaseGood) & 1;
+			const U64x2 tt = tab16(pos_tab, i * (kNumCodes * 16) + (e & kCodeOff));
 			fh ^= tt.x;
 			rh ^= tt.y;
-			cnt += ((e & (kBaseValid | kBaseStart)) == kBaseValid);
 		}
 	} else {
 		// Horner form (large k: the positional table would not fit in LDS)
-		uint32_t e = tile[li0];
-		first_valid = (e >> 3) & 1;
-		U64x2 tt = sh.init_tab[e & kCodeMask];
-		fh = tt.x;
-		rh = tt.y;
-		for (uint32_t i = 1; i < k; ++i) {
-			e = tile[li0 + i];
-			tt = sh.init_tab[e & kCodeMask];
+		for (; i + 4 <= k; i += 4) {
+			const uint32_t w = lds_u32(bp + i);
+			good += __popc(w & (kBaseGood * 0x01010101u));
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				const U64x2 tt = tab16(sh.init_tab, (w >> (8 * b)) & kCodeOff);
+				fh = srol1(fh) ^ tt.x;
+				rh = sror1(rh) ^ tt.y;
+			}
+		}
+		for (; i < k; ++i) {
+			const uint32_t e = bp[i];
+			good += (e / kBaseGood) & 1;
+			const U64x2 tt = tab16(sh.init_tab, e & kCodeOff);
 			fh = srol1(fh) ^ tt.x;
 			rh = sror1(rh) ^ tt.y;
-			cnt += ((e & (kBaseValid | kBaseStart)) == kBaseValid);
 		}
 	}
+	// bases leaving (ob: li0 .. li0+7) and entering (ib: li0+k .. li0+k+7) the lane's windows
+	const uint64_t ob = lds_u64(bp), ib = lds_u64(bp + k);
+	uint32_t first_valid = (uint32_t)ob & kBaseValid;
+	good -= ((uint32_t)ob / kBaseGood) & 1;
 #pragma unroll
 	for (int w = 0; w < KW; ++w) {
 		if (w > 0) {
-			const uint32_t eo = tile[li0 + w - 1];
-			const uint32_t ei = tile[li0 + w - 1 + k];
-			const uint32_t en = tile[li0 + w];
-			const U64x2 ti = sh.in_tab[ei & kCodeMask];
-			const U64x2 to = sh.out_tab[eo & kCodeMask];
-			fh = srol1(fh) ^ ti.x ^ to.x;
-			rh = sror1(rh ^ ti.y ^ to.y);
-			cnt += ((ei & (kBaseValid | kBaseStart)) == kBaseValid);
-			cnt -= ((en & (kBaseValid | kBaseStart)) == kBaseValid);
-			first_valid = (en >> 3) & 1;
+			const uint32_t eo = (uint32_t)(ob >> (8 * (w - 1))) & 0xffu;
+			const uint32_t ei = (uint32_t)(ib >> (8 * (w - 1))) & 0xffu;
+			const uint32_t en = (uint32_t)(ob >> (8 * w)) & 0xffu;
+			const U64x2 tt = tab16(sh.pair_tab, ((eo & kCodeOff) * kNumCodes) | (ei & kCodeOff));
+			fh = srol1(fh) ^ tt.x;
+			rh = sror1(rh ^ tt.y);
+			good += (ei / kBaseGood) & 1;
+			good -= (en / kBaseGood) & 1;
+			first_valid = en & kBaseValid;
 		}
-		const bool ok = first_valid && cnt == k - 1;
+		const bool ok = first_valid && good == k - 1;
 		WinHash<SPACED> wh;
 		wh.kms = hp.kms;
 		wh.stn = 0;
@@ -268,8 +304,8 @@ __device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqS
 			for (uint32_t j = 0; j < hp.n_seeds; ++j) {
 				uint64_t fs = fh, rs = rh;
 				for (uint32_t d = hp.dc_off[j]; d < hp.dc_off[j + 1]; ++d) {
-					const uint32_t i = dc_idx[d];
-					const U64x2 tt = pos_tab[i * kNumCodes + (tile[li0 + w + i] & kCodeMask)];
+					const uint32_t di = dc_idx[d];
+					const U64x2 tt = tab16(pos_tab, di * (kNumCodes * 16) + (bp[w + di] & kCodeOff));
 					fs ^= tt.x;
 					rs ^= tt.y;
 				}
