@@ -10,8 +10,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "_build")
-LIB = os.path.join(HERE, "libbtlbf.so")
+# BTLBF_BUILD_TAG=<tag> (with BTLBF_CXXFLAGS) builds a diagnostic variant next to the product library
+TAG = os.environ.get("BTLBF_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "_build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(HERE, "libbtlbf%s.so" % ("_" + TAG if TAG else ""))
 HEADERS = ["internal.hpp", "device_utils.hpp", "seq_core.hpp", "partition_core.hpp",
            os.path.join("..", "..", "include", "btlbf.h")]
 # (object name, source, extra flags): pass A of the partitioned pipeline is one unit per hash count

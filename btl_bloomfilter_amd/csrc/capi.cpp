@@ -1003,7 +1003,7 @@ struct PartPlan {
 uint32_t chunks_for(double mean_entries, uint32_t tail_chunks)
 {
 	const double m = mean_entries + 8.0 * std::sqrt(mean_entries + 1.0) + 32.0;
-	return (uint32_t)std::min<double>(4.0e9, std::ceil(m / 32.0)) + tail_chunks;
+	return (uint32_t)std::min<double>(4.0e9, std::ceil(m / (double)kChunk)) + tail_chunks;
 }
 
 unsigned ceil_log2(uint64_t x)
@@ -1066,7 +1066,7 @@ void plan_caps(PartPlan& pl, double entries, int first_level)
 		l.cap = chunks_for(entries / (useful * l.regions), 1);
 		l.alloc_bins = j == 1 && pl.group_bins ? pl.group_bins * l.P : l.bins;
 		l.cnt_bytes = ((uint64_t)l.alloc_bins * l.regions * 4 + 255) / 256 * 256;
-		l.ent_bytes = (uint64_t)l.alloc_bins * l.regions * l.cap * 128;
+		l.ent_bytes = (uint64_t)l.alloc_bins * l.regions * l.cap * (kChunk * 4);
 		pl.bytes_total += l.cnt_bytes + l.ent_bytes;
 	}
 }
@@ -1384,7 +1384,7 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 // The GLOBAL filter (size = f->mod.size, a power of two) is cut into 1024 level-0 bins; with W shards
 // owner g holds bins [g*1024/W, (g+1)*1024/W).  An origin partitions its probes into those bins (pass
 // A, regions = its CU count); the block of one owner is contiguous, so the exchange is a fixed-size
-// all-to-all of [1024/W bins][regions][cap][32] uint32 plus the entry counts.
+// all-to-all of [1024/W bins][regions][cap][kChunk] uint32 plus the entry counts.
 struct RoutePlan {
 	uint32_t bins = 1024; // level-0 bins over the global position space
 	uint32_t shift0 = 0;  // log2(positions per level-0 bin)
@@ -1417,7 +1417,7 @@ int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, uns
 	const uint64_t tile_w = (uint64_t)part_tile_windows();
 	const double entries = (double)((len + tile_w - 1) / tile_w) * probes_per_tile(f, lay);
 	rp.cap = chunks_for(entries / ((double)rp.bins * rp.regions), 1);
-	rp.ent_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * rp.cap * 128;
+	rp.ent_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * rp.cap * (kChunk * 4);
 	rp.cnt_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * 4;
 	return BTLBF_OK;
 }

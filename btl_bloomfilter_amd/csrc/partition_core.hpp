@@ -13,8 +13,8 @@ static constexpr int kPartW = 8;                        // windows per lane and 
 static constexpr int kPartHalf = 4;                     // ... partitioned in two rounds of 4 (the rings hold one)
 static constexpr int kPartTile = kPartThreads * kPartW; // windows per tile of pass A
 static constexpr int kApplyThreads = 512;
-static constexpr uint32_t kChunk = 32;           // entries per chunk
 static constexpr uint32_t kStageEntries = 32768; // LDS staging: 128 KiB of uint32 entries
+static constexpr uint32_t kFlushItems = kStageEntries / kChunk; // chunks the rings can hold = most one round flushes
 static constexpr uint32_t kPartLdsBudget = 160 * 1024 - 1536; // dynamic LDS a workgroup may ask for (static: SeqShared)
 
 // LDS image of the staged partitioner (carved from dynamic LDS by the kernels)
@@ -23,8 +23,7 @@ struct PartLds {
 	uint32_t* pt;      // [P] low 16 bits: entries in the ring (+ offered this round); high 16: ring write position
 	uint32_t* fl;      // [P] entries flushed from the bin this round (multiple of 32)
 	uint32_t* written; // [P] chunks written to this workgroup's region of the bin
-	uint32_t* fout;    // [1024] flush items, a private slice per wave: output chunk index ...
-	uint16_t* flist;   // [1024] ... and bin | ring chunk << 10
+	uint16_t* flist;   // [kFlushItems] flush items, a private slice per wave: bin | chunk of this round's flush << 10
 	uint32_t sc_shift; // log2(SC)
 };
 
@@ -38,7 +37,7 @@ __host__ __device__ inline uint32_t part_pow2ceil(uint32_t x)
 
 __host__ __device__ inline uint32_t part_lds_bytes(uint32_t P)
 {
-	return kStageEntries * 4 + 3 * P * 4 + 1024 * 4 + 1024 * 2 + 16;
+	return kStageEntries * 4 + 3 * P * 4 + kFlushItems * 2 + 16;
 }
 
 __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
@@ -48,8 +47,7 @@ __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
 	l.pt = l.stage + kStageEntries;
 	l.fl = l.pt + P;
 	l.written = l.fl + P;
-	l.fout = l.written + P;
-	l.flist = reinterpret_cast<uint16_t*>(l.fout + 1024);
+	l.flist = reinterpret_cast<uint16_t*>(l.written + P);
 	uint32_t pc = part_pow2ceil(P < 32 ? 32 : P), sh = 0;
 	while ((kStageEntries >> sh) > pc)
 		++sh; // kStageEntries / 2^sh == pc  ->  SC = 2^sh
@@ -151,27 +149,22 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 		// bins are owned by lanes (P <= NT): wave v owns bins [64v, 64v+64) and flushes them itself,
 		// through its private slice of the flush list -- no workgroup barrier in between
 		const uint32_t b = tid, lane = tid & 63;
-		uint32_t nfl = 0, hc = 0, o0 = 0, w0 = 0;
+		uint32_t nfl = 0;
 		if (b < P) {
 			const uint32_t w = l.pt[b];
 			const uint32_t occ = w & 0xffffu;           // ring content + everything offered this round
 			const uint32_t avail = occ < SC ? occ : SC; // entries that really sit in the ring
-			nfl = avail >> 5;
-			const uint32_t f = nfl << 5;
+			nfl = avail >> kChunkShift;
+			const uint32_t f = nfl << kChunkShift;
 			// state for the next round (see above)
 			const uint32_t tot = occ - f;
 			const uint32_t nocc = tot < SC ? tot : SC;
 			l.pt[b] = (((w >> 16) - (tot - nocc)) << 16) | nocc;
 			l.fl[b] = f;
-			if (nfl) {
-				w0 = l.written[b];
-				l.written[b] = w0 + nfl;
-				// read position of the ring: both halves of pt grew by the same amount this round
-				hc = (((w >> 16) - occ) & ring) >> 5;
-				o0 = ((bin0 + b) * o.regions + region) * o.cap;
-			}
+			if (nfl)
+				l.written[b] += nfl;
 		}
-		// exclusive prefix sum of nfl over the wave -> slots in the wave's slice (2*SC items)
+		// exclusive prefix sum of nfl over the wave -> slots in the wave's slice (64 bins * SC/kChunk items)
 		uint32_t incl = nfl;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
@@ -180,23 +173,27 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 				incl += t;
 		}
 		const uint32_t total = __shfl(incl, 63, 64);
-		const uint32_t slice = (tid >> 6) * (2u << l.sc_shift);
-		for (uint32_t c = 0; c < nfl; ++c) {
-			const uint32_t j = slice + incl - nfl + c;
-			l.flist[j] = (uint16_t)(b | (((hc + c) & (ring >> 5)) << 10));
-			l.fout[j] = w0 + c < o.cap ? o0 + w0 + c : 0xffffffffu;
-		}
+		const uint32_t slice = (tid >> 6) * ((64u / kChunk) << l.sc_shift);
+		for (uint32_t c = 0; c < nfl; ++c)
+			l.flist[slice + incl - nfl + c] = (uint16_t)(b | (c << 10));
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		// 8 lanes per chunk, 16 bytes per lane -> one aligned 128-byte line per chunk
-		const uint32_t l8 = lane & 7;
-		for (uint32_t j = lane >> 3; j < total; j += 8) {
-			const uint32_t it = l.flist[slice + j], oc = l.fout[slice + j];
-			const uint32_t fb = it & 1023, rc = it >> 10;
-			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(fb << l.sc_shift) + (rc << 5) + l8 * 4]);
-			if (oc != 0xffffffffu) {
-				*reinterpret_cast<uint4*>(&o.ent[(uint64_t)oc * kChunk + l8 * 4]) = v;
+		// 4 lanes per chunk, 16 bytes per lane -> one aligned 64-byte line per chunk.  Where the chunk
+		// sits in the ring and in the region follows from the bin's (already updated) state:
+		//   ring read position before the flush = new write position - new occupancy - flushed
+		//   chunks written before the flush     = written - flushed chunks
+		const uint32_t l4 = lane & 3;
+		for (uint32_t j = lane >> 2; j < total; j += 16) {
+			const uint32_t it = l.flist[slice + j];
+			const uint32_t fb = it & 1023, c = it >> 10;
+			const uint32_t w = l.pt[fb], f = l.fl[fb];
+			const uint32_t rd = ((w >> 16) - (w & 0xffffu) - f + (c << kChunkShift)) & ring;
+			const uint32_t wc = l.written[fb] - (f >> kChunkShift) + c;
+			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(fb << l.sc_shift) + rd + l4 * 4]);
+			if (wc < o.cap) {
+				const uint64_t oc = (uint64_t)((bin0 + fb) * o.regions + region) * o.cap + wc;
+				*reinterpret_cast<uint4*>(&o.ent[oc * kChunk + l4 * 4]) = v;
 			} else {
 				ovf(fb, v.x);
 				ovf(fb, v.y);
@@ -228,25 +225,25 @@ __device__ __forceinline__ void part_finish(const PartLds& l, const PartOut& o, 
                                             OVF&& ovf)
 {
 	__syncthreads();
-	const uint32_t tid = threadIdx.x, lane32 = tid & 31;
+	const uint32_t tid = threadIdx.x, ln = tid & (kChunk - 1);
 	const uint32_t ring = (1u << l.sc_shift) - 1;
-	for (uint32_t b = tid >> 5; b < o.P; b += NT / 32) {
+	for (uint32_t b = tid / kChunk; b < o.P; b += NT / kChunk) {
 		const uint32_t w = l.pt[b], n = w & 0xffffu, hd = ((w >> 16) - n) & ring;
 		const uint32_t w0 = l.written[b];
 		const uint32_t full = w0 < o.cap ? w0 : o.cap; // chunks of this region that really hold data
-		const uint32_t o0 = ((bin0 + b) * o.regions + region) * o.cap;
+		const uint64_t o0 = (uint64_t)((bin0 + b) * o.regions + region) * o.cap;
 		uint32_t stored = 0;
 		for (uint32_t c = 0; c * kChunk < n; ++c) {
-			const uint32_t i = c * kChunk + lane32;
+			const uint32_t i = c * kChunk + ln;
 			const uint32_t v = i < n ? l.stage[(b << l.sc_shift) + ((hd + i) & ring)] : 0;
 			if (w0 + c < o.cap) {
-				o.ent[(uint64_t)(o0 + w0 + c) * kChunk + lane32] = v;
+				o.ent[(o0 + w0 + c) * kChunk + ln] = v;
 				stored = (c + 1) * kChunk < n ? (c + 1) * kChunk : n;
 			} else if (i < n) {
 				ovf(b, v);
 			}
 		}
-		if (lane32 == 0)
+		if (ln == 0)
 			o.cnt[(bin0 + b) * o.regions + region] = full * kChunk + stored;
 	}
 }

@@ -101,6 +101,20 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 // one workgroup per segment (= input bin `seg`); pos_base + (seg << seg_shift | entry) is the
 // position reported for failed tests
 // Input bin blockIdx.x holds the entries of segment seg_first + blockIdx.x (group-relative numbering).
+static constexpr uint32_t kApplyMaxRegions = 1024; // region table kept in LDS (more: plain loop)
+
+template <bool QUERY>
+__device__ __forceinline__ void apply_entry(uint32_t* lds, uint32_t e, const PartSide& sd, uint64_t seg_base)
+{
+	if (!QUERY)
+		atomicOr(&lds[e >> 5], 1u << (e & 31));
+	else if (!((lds[e >> 5] >> (e & 31)) & 1u))
+		part_report_fail(sd, sd.pos_base + (seg_base | e));
+}
+
+// Memory-level parallelism is what this kernel lives on (two workgroups per CU): the segment is
+// fetched with 8 independent 16-byte loads per thread, and the entries of ALL regions are walked as
+// one virtual array with 4 independent loads per thread in flight.
 template <bool QUERY>
 __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
                                                                  uint32_t seg_shift, uint32_t seg_first,
@@ -108,16 +122,29 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	__shared__ uint32_t any;
+	__shared__ uint32_t r_nev[kApplyMaxRegions]; // 16-byte vectors of entries in region r of this bin
+	__shared__ uint32_t r_reg[kApplyMaxRegions]; // its index into in.cnt / in.ent
 	const uint32_t tid = threadIdx.x;
 	const uint32_t ibin = blockIdx.x;
 	const uint32_t seg = seg_first + blockIdx.x;
 	const uint32_t n_regions = in.blocks * in.regions_per_block;
+	const uint32_t cap_entries = in.cap * kChunk;
+	const bool tabled = n_regions <= kApplyMaxRegions;
 	if (tid == 0)
 		any = 0;
 	__syncthreads();
 	uint32_t mine = 0;
-	for (uint32_t r = tid; r < n_regions; r += kApplyThreads)
-		mine |= in.cnt[part_in_region(in, ibin, r)];
+	for (uint32_t r = tid; r < n_regions; r += kApplyThreads) {
+		const uint32_t reg = part_in_region(in, ibin, r);
+		uint32_t n = in.cnt[reg];
+		if (n > cap_entries)
+			n = cap_entries;
+		mine |= n;
+		if (tabled) {
+			r_nev[r] = n; // entries for now; the tail test needs them
+			r_reg[r] = reg;
+		}
+	}
 	if (mine)
 		any = 1;
 	__syncthreads();
@@ -125,42 +152,107 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 		return; // untouched segment: no traffic at all
 	const uint64_t seg_bytes = 1ull << (seg_shift - 3);
 	const uint64_t byte0 = (uint64_t)seg * seg_bytes;
+	const uint64_t seg_base = (uint64_t)seg << seg_shift;
 	uint64_t nbytes = local_bytes - byte0;
 	if (nbytes > seg_bytes)
 		nbytes = seg_bytes;
 	const uint32_t n_vec = (uint32_t)((nbytes + 15) / 16); // the allocation is padded to 16 bytes
 	uint4* lds4 = reinterpret_cast<uint4*>(dyn);
 	uint4* g4 = reinterpret_cast<uint4*>(filter + byte0);
-	for (uint32_t i = tid; i < n_vec; i += kApplyThreads)
-		lds4[i] = g4[i];
+	constexpr int kSegU = 8;
+	for (uint32_t base = 0; base < n_vec; base += kApplyThreads * kSegU) {
+		uint4 v[kSegU];
+#pragma unroll
+		for (int u = 0; u < kSegU; ++u) {
+			const uint32_t i = base + (uint32_t)u * kApplyThreads + tid;
+			v[u] = make_uint4(0, 0, 0, 0);
+			if (i < n_vec)
+				v[u] = g4[i];
+		}
+#pragma unroll
+		for (int u = 0; u < kSegU; ++u) {
+			const uint32_t i = base + (uint32_t)u * kApplyThreads + tid;
+			if (i < n_vec)
+				lds4[i] = v[u];
+		}
+	}
 	__syncthreads();
 	uint32_t* lds = reinterpret_cast<uint32_t*>(dyn);
-	for (uint32_t r = 0; r < n_regions; ++r) {
-		const uint32_t reg = part_in_region(in, ibin, r);
-		uint32_t n = in.cnt[reg];
-		if (n > in.cap * kChunk)
-			n = in.cap * kChunk;
-		const uint4* e4 = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg * in.cap * kChunk);
-		const uint32_t n_ev = (n + 3) / 4;
-		for (uint32_t i = tid; i < n_ev; i += kApplyThreads) {
-			const uint4 q = e4[i];
-			const uint32_t e[4] = {q.x, q.y, q.z, q.w};
+	if (tabled) {
+		// kEntU walkers per thread over the virtual concatenation of the regions' vectors
+		constexpr int kEntU = 4;
+		uint32_t wr[kEntU], wi[kEntU];
+		// move walker (r, i) forward to the region that holds its virtual vector index
+#define BTLBF_SETTLE(r, i)                               \
+	while ((r) < n_regions) {                            \
+		const uint32_t nev__ = (r_nev[(r)] + 3) / 4;     \
+		if ((i) < nev__)                                 \
+			break;                                       \
+		(i) -= nev__;                                    \
+		++(r);                                           \
+	}
 #pragma unroll
-			for (int c = 0; c < 4; ++c) {
-				if (i * 4 + c >= n)
-					continue;
-				if (!QUERY)
-					atomicOr(&lds[e[c] >> 5], 1u << (e[c] & 31));
-				else if (!((lds[e[c] >> 5] >> (e[c] & 31)) & 1u))
-					part_report_fail(sd, sd.pos_base + (((uint64_t)seg << seg_shift) | e[c]));
+		for (int u = 0; u < kEntU; ++u) {
+			wr[u] = 0;
+			wi[u] = (uint32_t)u * kApplyThreads + tid;
+			BTLBF_SETTLE(wr[u], wi[u])
+		}
+		while (wr[0] < n_regions) {
+			uint4 q[kEntU];
+			uint32_t left[kEntU]; // entries of the region from this vector on (0: walker finished)
+#pragma unroll
+			for (int u = 0; u < kEntU; ++u) {
+				left[u] = 0;
+				q[u] = make_uint4(0, 0, 0, 0);
+				if (wr[u] < n_regions) {
+					left[u] = r_nev[wr[u]] - wi[u] * 4;
+					q[u] = reinterpret_cast<const uint4*>(in.ent + (uint64_t)r_reg[wr[u]] * cap_entries)[wi[u]];
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < kEntU; ++u) {
+				if (left[u] > 0)
+					apply_entry<QUERY>(lds, q[u].x, sd, seg_base);
+				if (left[u] > 1)
+					apply_entry<QUERY>(lds, q[u].y, sd, seg_base);
+				if (left[u] > 2)
+					apply_entry<QUERY>(lds, q[u].z, sd, seg_base);
+				if (left[u] > 3)
+					apply_entry<QUERY>(lds, q[u].w, sd, seg_base);
+				wi[u] += kEntU * kApplyThreads;
+				BTLBF_SETTLE(wr[u], wi[u])
+			}
+		}
+#undef BTLBF_SETTLE
+	} else {
+		for (uint32_t r = 0; r < n_regions; ++r) {
+			const uint32_t reg = part_in_region(in, ibin, r);
+			uint32_t n = in.cnt[reg];
+			if (n > cap_entries)
+				n = cap_entries;
+			const uint4* e4 = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg * cap_entries);
+			const uint32_t n_ev = (n + 3) / 4;
+			for (uint32_t i = tid; i < n_ev; i += kApplyThreads) {
+				const uint4 q = e4[i];
+				const uint32_t e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+				for (int c = 0; c < 4; ++c)
+					if (i * 4 + c < n)
+						apply_entry<QUERY>(lds, e[c], sd, seg_base);
 			}
 		}
 	}
 	if (QUERY)
 		return; // read-only sweep
 	__syncthreads();
-	for (uint32_t i = tid; i < n_vec; i += kApplyThreads)
-		g4[i] = lds4[i];
+	for (uint32_t base = 0; base < n_vec; base += kApplyThreads * kSegU) {
+#pragma unroll
+		for (int u = 0; u < kSegU; ++u) {
+			const uint32_t i = base + (uint32_t)u * kApplyThreads + tid;
+			if (i < n_vec)
+				g4[i] = lds4[i];
+		}
+	}
 }
 
 // ---- launchers -----------------------------------------------------------------------------------

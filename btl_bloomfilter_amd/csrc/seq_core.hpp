@@ -137,10 +137,7 @@ __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_
 	__syncthreads(); // previous tile fully consumed (and tables written, first time round)
 
 	// words past the data are zero-filled so no stale flags survive
-	for (uint32_t j = tid; j < tile_cap / 4; j += NT) {
-		uint32_t raw = 0;
-		if (j < n_words)
-			raw = *reinterpret_cast<const uint32_t*>(seq + g0 - mis + 4ull * j);
+	auto convert = [&](uint32_t j, uint32_t raw) {
 		// position of this word's first byte relative to g0 (negative for the misaligned head)
 		const int32_t rel0 = (int32_t)(4 * j) - (int32_t)mis;
 		uint32_t r = 0; // offset within its read of the word's first byte (uniform layout only)
@@ -161,6 +158,29 @@ __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_
 			o |= e << (8 * b);
 		}
 		reinterpret_cast<uint32_t*>(tile)[j] = o;
+	};
+	// the thread's first words are all requested before any is converted (one memory latency per
+	// tile, not one per word)
+	constexpr int kAhead = KW / 4 + 1;
+	uint32_t raw[kAhead];
+#pragma unroll
+	for (int a = 0; a < kAhead; ++a) {
+		const uint32_t j = tid + (uint32_t)a * NT;
+		raw[a] = 0;
+		if (j < n_words)
+			raw[a] = *reinterpret_cast<const uint32_t*>(seq + g0 - mis + 4ull * j);
+	}
+#pragma unroll
+	for (int a = 0; a < kAhead; ++a) {
+		const uint32_t j = tid + (uint32_t)a * NT;
+		if (j < tile_cap / 4)
+			convert(j, raw[a]);
+	}
+	for (uint32_t j = tid + kAhead * NT; j < tile_cap / 4; j += NT) { // large k only
+		uint32_t w = 0;
+		if (j < n_words)
+			w = *reinterpret_cast<const uint32_t*>(seq + g0 - mis + 4ull * j);
+		convert(j, w);
 	}
 	if (starts) {
 		// first index s with starts[s] > g0: every boundary strictly inside (g0, g0+need) matters
