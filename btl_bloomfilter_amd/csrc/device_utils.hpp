@@ -125,6 +125,20 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
 	return z ^ (z >> 31);
 }
 
+// inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside each row of 16 lanes with DPP
+// row shifts, then the row totals are broadcast down (row_bcast:15 into rows 1 and 3, row_bcast:31
+// into rows 2 and 3) -- six VALU adds, no LDS traffic
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+	return v;
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
 	for (int o = 32; o > 0; o >>= 1)

@@ -164,15 +164,10 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 			if (nfl)
 				l.written[b] += nfl;
 		}
-		// exclusive prefix sum of nfl over the wave -> slots in the wave's slice (64 bins * SC/kChunk items)
-		uint32_t incl = nfl;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t t = __shfl_up(incl, d, 64);
-			if (lane >= (uint32_t)d)
-				incl += t;
-		}
-		const uint32_t total = __shfl(incl, 63, 64);
+		// inclusive prefix sum of nfl over the wave (DPP row shifts + row broadcasts, no LDS) -> slots
+		// in the wave's slice (64 bins * SC/kChunk items)
+		const uint32_t incl = wave_scan_incl(nfl);
+		const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
 		const uint32_t slice = (tid >> 6) * ((64u / kChunk) << l.sc_shift);
 		for (uint32_t c = 0; c < nfl; ++c)
 			l.flist[slice + incl - nfl + c] = (uint16_t)(b | (c << 10));
@@ -220,6 +215,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 }
 
 // flush whatever is staged and publish the ENTRY count of this workgroup's region of every bin
+// (exact; the data itself is padded to a multiple of 4 entries, see below)
 template <int NT, class OVF>
 __device__ __forceinline__ void part_finish(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
                                             OVF&& ovf)
@@ -235,7 +231,10 @@ __device__ __forceinline__ void part_finish(const PartLds& l, const PartOut& o, 
 		uint32_t stored = 0;
 		for (uint32_t c = 0; c * kChunk < n; ++c) {
 			const uint32_t i = c * kChunk + ln;
-			const uint32_t v = i < n ? l.stage[(b << l.sc_shift) + ((hd + i) & ring)] : 0;
+			// the tail is padded to a whole 16-byte vector with copies of the last entry: readers
+			// take whole vectors, and a repeated position changes nothing for OR / test
+			const uint32_t src = i < n ? i : n - 1;
+			const uint32_t v = i < ((n + 3) & ~3u) ? l.stage[(b << l.sc_shift) + ((hd + src) & ring)] : 0;
 			if (w0 + c < o.cap) {
 				o.ent[(o0 + w0 + c) * kChunk + ln] = v;
 				stored = (c + 1) * kChunk < n ? (c + 1) * kChunk : n;

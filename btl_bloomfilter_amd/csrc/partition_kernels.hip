@@ -81,17 +81,17 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 #pragma unroll
 			for (int v = 0; v < kVec; ++v) {
 				const uint32_t e4[4] = {nxt[v].x, nxt[v].y, nxt[v].z, nxt[v].w};
-				const uint32_t i0 = (base + (uint32_t)v * kPartThreads + tid) * 4;
+				// whole vectors: a region's tail is padded with copies of its last entry (part_finish)
+				live |= (uint32_t)(base + (uint32_t)v * kPartThreads + tid < n_vec) << v;
 #pragma unroll
 				for (int c = 0; c < 4; ++c) {
 					bin[v * 4 + c] = e4[c] >> sub_shift;
 					val[v * 4 + c] = e4[c] & sub_mask;
-					live |= (uint32_t)(i0 + c < n) << (v * 4 + c);
 				}
 				const uint32_t i = base + kPartThreads * kVec + (uint32_t)v * kPartThreads + tid;
 				nxt[v] = i < n_vec ? src[i] : make_uint4(0, 0, 0, 0);
 			}
-			part_round<kPartThreads, kVec * 4, 1>(pl, out, bin0, g, bin, val, live, ovf STAMP_PASS);
+			part_round<kPartThreads, kVec * 4, 4>(pl, out, bin0, g, bin, val, live, ovf STAMP_PASS);
 		}
 	}
 	part_finish<kPartThreads>(pl, out, bin0, g, ovf);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 			n = cap_entries;
 		mine |= n;
 		if (tabled) {
-			r_nev[r] = n; // entries for now; the tail test needs them
+			r_nev[r] = (n + 3) / 4; // whole vectors: the tail is padded with copies of the last entry
 			r_reg[r] = reg;
 		}
 	}
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 		// move walker (r, i) forward to the region that holds its virtual vector index
 #define BTLBF_SETTLE(r, i)                               \
 	while ((r) < n_regions) {                            \
-		const uint32_t nev__ = (r_nev[(r)] + 3) / 4;     \
+		const uint32_t nev__ = r_nev[(r)];               \
 		if ((i) < nev__)                                 \
 			break;                                       \
 		(i) -= nev__;                                    \
@@ -199,26 +199,22 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 		}
 		while (wr[0] < n_regions) {
 			uint4 q[kEntU];
-			uint32_t left[kEntU]; // entries of the region from this vector on (0: walker finished)
+			bool on[kEntU];
 #pragma unroll
 			for (int u = 0; u < kEntU; ++u) {
-				left[u] = 0;
+				on[u] = wr[u] < n_regions;
 				q[u] = make_uint4(0, 0, 0, 0);
-				if (wr[u] < n_regions) {
-					left[u] = r_nev[wr[u]] - wi[u] * 4;
+				if (on[u])
 					q[u] = reinterpret_cast<const uint4*>(in.ent + (uint64_t)r_reg[wr[u]] * cap_entries)[wi[u]];
-				}
 			}
 #pragma unroll
 			for (int u = 0; u < kEntU; ++u) {
-				if (left[u] > 0)
+				if (on[u]) {
 					apply_entry<QUERY>(lds, q[u].x, sd, seg_base);
-				if (left[u] > 1)
 					apply_entry<QUERY>(lds, q[u].y, sd, seg_base);
-				if (left[u] > 2)
 					apply_entry<QUERY>(lds, q[u].z, sd, seg_base);
-				if (left[u] > 3)
 					apply_entry<QUERY>(lds, q[u].w, sd, seg_base);
+				}
 				wi[u] += kEntU * kApplyThreads;
 				BTLBF_SETTLE(wr[u], wi[u])
 			}
@@ -234,11 +230,10 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 			const uint32_t n_ev = (n + 3) / 4;
 			for (uint32_t i = tid; i < n_ev; i += kApplyThreads) {
 				const uint4 q = e4[i];
-				const uint32_t e[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-				for (int c = 0; c < 4; ++c)
-					if (i * 4 + c < n)
-						apply_entry<QUERY>(lds, e[c], sd, seg_base);
+				apply_entry<QUERY>(lds, q.x, sd, seg_base);
+				apply_entry<QUERY>(lds, q.y, sd, seg_base);
+				apply_entry<QUERY>(lds, q.z, sd, seg_base);
+				apply_entry<QUERY>(lds, q.w, sd, seg_base);
 			}
 		}
 	}
