@@ -46,11 +46,12 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 		tile_off = (uint32_t)((t_begin * (uint64_t)kPartTile) % L);
 	const uint32_t tile_step = L ? (uint32_t)(kPartTile % L) : 0;
 
+	__syncthreads(); // tables and partition state ready
 	STAMP_DECL;
 	for (uint64_t t = t_begin; t < t_end; ++t) {
 		const uint64_t g0 = t * (uint64_t)kPartTile;
 		STAMP(0);
-		const uint32_t mis = seq_stage_tile<kPartThreads, kPartW>(tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+		const uint32_t mis = seq_stage_tile<kPartThreads, kPartW, false>(tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
 		STAMP(1);
 

@@ -179,22 +179,33 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 		//   ring read position before the flush = new write position - new occupancy - flushed
 		//   chunks written before the flush     = written - flushed chunks
 		const uint32_t l4 = lane & 3;
-		for (uint32_t j = lane >> 2; j < total; j += 16) {
+		auto item = [&](uint32_t j, uint32_t& fb, uint32_t& src, uint64_t& dst, bool& fits) {
 			const uint32_t it = l.flist[slice + j];
-			const uint32_t fb = it & 1023, c = it >> 10;
+			fb = it & 1023;
+			const uint32_t c = it >> 10;
 			const uint32_t w = l.pt[fb], f = l.fl[fb];
 			const uint32_t rd = ((w >> 16) - (w & 0xffffu) - f + (c << kChunkShift)) & ring;
 			const uint32_t wc = l.written[fb] - (f >> kChunkShift) + c;
-			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(fb << l.sc_shift) + rd + l4 * 4]);
-			if (wc < o.cap) {
-				const uint64_t oc = (uint64_t)((bin0 + fb) * o.regions + region) * o.cap + wc;
-				*reinterpret_cast<uint4*>(&o.ent[oc * kChunk + l4 * 4]) = v;
+			src = (fb << l.sc_shift) + rd + l4 * 4;
+			fits = wc < o.cap;
+			dst = ((uint64_t)((bin0 + fb) * o.regions + region) * o.cap + wc) * kChunk + l4 * 4;
+		};
+		auto emit = [&](uint32_t fb, const uint4& v, uint64_t dst, bool fits) {
+			if (fits) {
+				*reinterpret_cast<uint4*>(&o.ent[dst]) = v;
 			} else {
 				ovf(fb, v.x);
 				ovf(fb, v.y);
 				ovf(fb, v.z);
 				ovf(fb, v.w);
 			}
+		};
+		for (uint32_t j = lane >> 2; j < total; j += 16) {
+			uint32_t fb, src;
+			uint64_t dst;
+			bool fits;
+			item(j, fb, src, dst, fits);
+			emit(fb, *reinterpret_cast<const uint4*>(&l.stage[src]), dst, fits);
 		}
 	}
 	__syncthreads();

@@ -118,7 +118,9 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t x, uint32_t L, uint32_t i
 // Ends with a __syncthreads(); begins with one so that the previous tile has been fully consumed.
 // tile_off = g0 % read_len (uniform layout only).  Returns the misalignment `mis` (0..3): the LDS
 // index of window w's first base is w + mis.
-template <int NT, int KW = kW>
+// LEAD_BARRIER = false: the caller guarantees that nobody still reads the previous tile (pass A of
+// the partitioned pipeline: its last partition round ends with a barrier after the last tile read).
+template <int NT, int KW = kW, bool LEAD_BARRIER = true>
 __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_cap, SeqShared& sh,
                                                    const uint8_t* seq, uint64_t len, const LayoutParams& lay,
                                                    uint32_t k, uint64_t g0, uint32_t tile_off)
@@ -134,7 +136,8 @@ __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_
 	const uint32_t n_words = (mis + (uint32_t)need + 3) / 4;
 	const bool uniform = !starts && L;
 	const uint32_t inv = uniform ? 0xffffffffu / L : 0;
-	__syncthreads(); // previous tile fully consumed (and tables written, first time round)
+	if (LEAD_BARRIER)
+		__syncthreads(); // previous tile fully consumed (and tables written, first time round)
 
 	// words past the data are zero-filled so no stale flags survive
 	auto convert = [&](uint32_t j, uint32_t raw) {
