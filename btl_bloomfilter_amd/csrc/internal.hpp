@@ -27,9 +27,11 @@ static constexpr unsigned kNumCodes = 8u;
 static constexpr unsigned kBaseValid = 1u;
 static constexpr unsigned kBaseGood = 2u;
 
-// partitioned pipeline: entries leave the LDS rings as CHUNKS of kChunk uint32 (one aligned 64-byte line)
-static constexpr uint32_t kChunk = 16;
-static constexpr uint32_t kChunkShift = 4;
+// partitioned pipeline: entries leave the LDS rings as CHUNKS of kChunk uint32 = one aligned 128-byte line
+// (64-byte chunks were measured: fewer late entries, but the HBM write traffic of pass A rose 22 % above
+// the bytes stored -- half-line writes are not free on this memory system)
+static constexpr uint32_t kChunk = 32;
+static constexpr uint32_t kChunkShift = 5;
 
 static constexpr int kMaxHash = 32;  // hash_num supported by the fused kernels
 static constexpr int kMaxSeeds = 16; // spaced seeds per filter

@@ -174,11 +174,12 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		// 4 lanes per chunk, 16 bytes per lane -> one aligned 64-byte line per chunk.  Where the chunk
+		// kChunk/4 lanes per chunk, 16 bytes per lane -> one aligned line per chunk.  Where the chunk
 		// sits in the ring and in the region follows from the bin's (already updated) state:
 		//   ring read position before the flush = new write position - new occupancy - flushed
 		//   chunks written before the flush     = written - flushed chunks
-		const uint32_t l4 = lane & 3;
+		constexpr uint32_t kLanesPerChunk = kChunk / 4;
+		const uint32_t l4 = lane & (kLanesPerChunk - 1);
 		auto item = [&](uint32_t j, uint32_t& fb, uint32_t& src, uint64_t& dst, bool& fits) {
 			const uint32_t it = l.flist[slice + j];
 			fb = it & 1023;
@@ -200,7 +201,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 				ovf(fb, v.w);
 			}
 		};
-		for (uint32_t j = lane >> 2; j < total; j += 16) {
+		for (uint32_t j = lane / kLanesPerChunk; j < total; j += 64 / kLanesPerChunk) {
 			uint32_t fb, src;
 			uint64_t dst;
 			bool fits;

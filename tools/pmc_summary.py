@@ -34,10 +34,12 @@ def slot_of(name):
 
 
 def is_query(name):
-    # the last template argument of the partition kernels is QUERY
+    # QUERY is the 4th template argument of part_hash_kernel<H, POW2, SPACED, QUERY, WINDOW> and the only
+    # one of part_split_kernel / part_apply_kernel
     args = name[name.find("<") + 1:name.find(">(")] if "<" in name else ""
-    last = args.split(",")[-1].strip()
-    return last in ("true", "(bool)1", "1")
+    parts = [a.strip() for a in args.split(",")]
+    q = parts[3] if "part_hash_kernel" in name and len(parts) > 3 else parts[-1]
+    return q in ("true", "(bool)1", "1")
 
 
 def collect(d, counter):
