@@ -22,6 +22,15 @@ class Layout(C.Structure):
     _fields_ = [("starts", C.c_void_p), ("n_seqs", C.c_uint64), ("read_len", C.c_uint32)]
 
 
+class FastxStats(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_bases", C.c_uint64), ("n_windows", C.c_uint64),
+                ("n_hits", C.c_uint64), ("n_batches", C.c_uint64), ("seconds_parse", C.c_double),
+                ("seconds_total", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class BtlbfError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("btlbf error %d: %s" % (code, msg))
@@ -93,6 +102,12 @@ _PROTOS = {
     "btlbf_and_answers": (C.c_int, [_P, _P, C.c_uint64, C.c_uint, _P, C.c_int, _P]),
     "btlbf_synth_reads": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_int, _P]),
     "btlbf_microbench": (C.c_int, [_P, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "btlbf_fastx_open": (C.c_int, [C.POINTER(_P), C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "btlbf_fastx_next": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "btlbf_fastx_records": (C.c_uint64, [_P]),
+    "btlbf_fastx_close": (None, [_P]),
+    "btlbf_insert_fastx": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint64, C.POINTER(FastxStats)]),
+    "btlbf_contains_fastx": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint64, C.POINTER(FastxStats)]),
 }
 EXPORTS = sorted(_PROTOS)
 

@@ -14,10 +14,10 @@ CSRC = os.path.join(HERE, "csrc")
 TAG = os.environ.get("BTLBF_BUILD_TAG", "")
 OBJ = os.path.join(HERE, "_build" + ("_" + TAG if TAG else ""))
 LIB = os.path.join(HERE, "libbtlbf%s.so" % ("_" + TAG if TAG else ""))
-HEADERS = ["internal.hpp", "device_utils.hpp", "seq_core.hpp", "partition_core.hpp",
+HEADERS = ["internal.hpp", "host_internal.hpp", "device_utils.hpp", "seq_core.hpp", "partition_core.hpp",
            os.path.join("..", "..", "include", "btlbf.h")]
 # (object name, source, extra flags): pass A of the partitioned pipeline is one unit per hash count
-UNITS = [("capi", "capi.cpp", []), ("seq_kernels", "seq_kernels.hip", []), ("aux_kernels", "aux_kernels.hip", []),
+UNITS = [("capi", "capi.cpp", []), ("fastx", "fastx.cpp", []), ("seq_kernels", "seq_kernels.hip", []), ("aux_kernels", "aux_kernels.hip", []),
          ("partition_kernels", "partition_kernels.hip", [])]
 UNITS += [("part_hash_h%d" % h, "part_hash_inst.hip", ["-DBTLBF_PART_H=%d" % h]) for h in range(1, 9)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -61,7 +61,7 @@ def build(force=False, verbose=False, jobs=None):
     jobs = jobs or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda u: _compile(u, hipcc, force, verbose), UNITS))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

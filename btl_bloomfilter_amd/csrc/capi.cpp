@@ -6,6 +6,7 @@
 // There is deliberately no CPU implementation of any compute entry point in this file.
 #include "../../include/btlbf.h"
 #include "internal.hpp"
+#include "host_internal.hpp"
 
 #include <algorithm>
 #include <cerrno>
@@ -28,6 +29,15 @@ using namespace btlbf;
 static thread_local char g_err[512] = "";
 
 static int fail(int code, const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+int btlbf_set_error(int code, const char* fmt, ...)
 {
 	va_list ap;
 	va_start(ap, fmt);

@@ -173,6 +173,23 @@ class _Filter:
         m = {"auto": 0, "direct": 1, "partitioned": 2}[mode] if isinstance(mode, str) else int(mode)
         check(self._L.btlbf_set_query_mode(self._h, m))
 
+    # -- FASTA / FASTQ files (btlbf_insert_fastx / btlbf_contains_fastx) -----------------------------
+    def insertFile(self, path, per_line=False, batch_bytes=0):
+        """Insert every k-mer of a FASTA / FASTQ / one-sequence-per-line file (optionally gzipped).
+        per_line=True treats every sequence line as its own sequence (the reference's loadBf);
+        the default concatenates the lines of a FASTA record (contigsToBloom).  Returns the stats dict."""
+        st = _lib.FastxStats()
+        check(self._L.btlbf_insert_fastx(self._h, str(path).encode(), 1 if per_line else 0, int(batch_bytes),
+                                         C.byref(st)))
+        return st.as_dict()
+
+    def containsFile(self, path, per_line=False, batch_bytes=0):
+        """Query every k-mer of a file; stats['n_windows'] clean windows, stats['n_hits'] of them found."""
+        st = _lib.FastxStats()
+        check(self._L.btlbf_contains_fastx(self._h, str(path).encode(), 1 if per_line else 0, int(batch_bytes),
+                                           C.byref(st)))
+        return st.as_dict()
+
     def setSpacedSeeds(self, seeds, h2=1):
         arr = (C.c_char_p * len(seeds))(*[s.encode() if isinstance(s, str) else s for s in seeds])
         check(self._L.btlbf_set_spaced_seeds(self._h, arr, len(seeds), h2))
@@ -429,3 +446,24 @@ def synth_reads_device(seed, first, n_reads, read_len, device=0, stream=None):
     check(_lib.load().btlbf_synth_reads(C.c_void_p(out.data_ptr()), seed, first, n_reads, read_len, device,
                                         _stream_ptr(stream)))
     return out
+
+
+def fastx_batches(path, k, per_line=False, batch_bytes=0, pageable=True):
+    """Iterate over the parser's batches as (bases: bytes, starts: list[int]) -- the host-side reader
+    behind insertFile (btlbf_fastx_open / btlbf_fastx_next); needs no GPU."""
+    L = _lib.load()
+    r = C.c_void_p()
+    flags = (1 if per_line else 0) | (2 if pageable else 0)
+    check(L.btlbf_fastx_open(C.byref(r), str(path).encode(), flags, int(k), int(batch_bytes)))
+    try:
+        while True:
+            b, s = C.c_void_p(), C.c_void_p()
+            nb, ns = C.c_uint64(), C.c_uint64()
+            check(L.btlbf_fastx_next(r, C.byref(b), C.byref(nb), C.byref(s), C.byref(ns)))
+            if ns.value == 0:
+                return
+            bases = C.string_at(b.value, nb.value) if nb.value else b""
+            starts = list((C.c_uint64 * (ns.value + 1)).from_address(s.value))
+            yield bases, starts
+    finally:
+        L.btlbf_fastx_close(r)

@@ -279,6 +279,47 @@ int btlbf_synth_reads(char* dev_out, uint64_t seed, uint64_t first_read, uint64_
  * returned in *n_done; *seconds = kernel time from HIP events */
 int btlbf_microbench(btlbf_filter* f, int kind, uint64_t n_access, uint64_t* n_done, double* seconds);
 
+/* ---- FASTA / FASTQ ingestion -------------------------------------------------
+ * Replaces the reference's toy loaders: Tests/AdHoc/ParallelFilter.cpp:104-122 (loadBf: header line +
+ * one sequence line, an ntHashIterator per line) and swig/writeBloom_rolling.cpp:18-59
+ * (contigsToBloom: the lines of a FASTA record are concatenated, then insertSeq).
+ * Input may be gzip-compressed.  Format by the first byte: '>' FASTA, '@' FASTQ (4-line records),
+ * anything else = one sequence per line. */
+enum btlbf_fastx_flags {
+	BTLBF_FASTX_RECORDS = 0,  /* the wrapped lines of a FASTA record form ONE sequence (contigsToBloom) */
+	BTLBF_FASTX_LINES = 1,    /* every sequence line is its own sequence (loadBf) */
+	BTLBF_FASTX_PAGEABLE = 2  /* do not pin the host buffers */
+};
+typedef struct btlbf_fastx btlbf_fastx;
+
+/* streaming parser: batches of at most batch_bytes sequence bytes (0 = 256 MiB) in the ragged layout
+ * of btlbf_layout; a sequence longer than a batch is cut with a k-1 base overlap so that every
+ * window appears in exactly one batch */
+int btlbf_fastx_open(btlbf_fastx** r, const char* path, uint32_t flags, uint32_t k, uint64_t batch_bytes);
+/* *bases (n_bases bytes) and *starts (n_seqs+1 offsets) stay valid until the call after the next
+ * one; n_seqs == 0 at end of input */
+int btlbf_fastx_next(btlbf_fastx* r, const char** bases, uint64_t* n_bases, const uint64_t** starts,
+                     uint64_t* n_seqs);
+uint64_t btlbf_fastx_records(const btlbf_fastx* r); /* records seen so far */
+void btlbf_fastx_close(btlbf_fastx* r);
+
+typedef struct btlbf_fastx_stats {
+	uint64_t n_records;  /* FASTA / FASTQ records (lines, for plain input) */
+	uint64_t n_bases;    /* sequence bytes sent to the GPU (overlaps of cut sequences included) */
+	uint64_t n_windows;  /* contains: clean k-mer windows tested */
+	uint64_t n_hits;     /* contains: windows found in the filter */
+	uint64_t n_batches;
+	double seconds_parse; /* host time inside the parser */
+	double seconds_total; /* wall time of the call */
+} btlbf_fastx_stats;
+
+/* whole file -> filter: pinned double buffers, copies on a copy stream, kernels on a compute stream;
+ * the host parses batch i+1 while batch i is copied and hashed.  stats may be NULL. */
+int btlbf_insert_fastx(btlbf_filter* f, const char* path, uint32_t flags, uint64_t batch_bytes,
+                       btlbf_fastx_stats* stats);
+int btlbf_contains_fastx(btlbf_filter* f, const char* path, uint32_t flags, uint64_t batch_bytes,
+                         btlbf_fastx_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

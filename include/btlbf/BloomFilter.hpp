@@ -108,6 +108,26 @@ class BloomFilter
 		btlbf_shim::check(btlbf_insert_seqs(m_f, seq.data(), seq.size(), nullptr, 0, BTLBF_ORDER_PARALLEL,
 		                                    BTLBF_HOST, nullptr));
 	}
+	// every k-mer of a FASTA / FASTQ / one-sequence-per-line file, gzip or plain (the job of the
+	// reference's loaders Tests/AdHoc/ParallelFilter.cpp:104-122 and swig/writeBloom_rolling.cpp:18-59);
+	// perLine: every sequence line is its own sequence instead of one sequence per FASTA record
+	btlbf_fastx_stats insertFile(const std::string& path, bool perLine = false, uint64_t batchBytes = 0)
+	{
+		flush();
+		btlbf_fastx_stats st;
+		btlbf_shim::check(btlbf_insert_fastx(m_f, path.c_str(), perLine ? BTLBF_FASTX_LINES : BTLBF_FASTX_RECORDS,
+		                                     batchBytes, &st));
+		return st;
+	}
+	// st.n_windows clean k-mers of the file, st.n_hits of them in the filter
+	btlbf_fastx_stats containsFile(const std::string& path, bool perLine = false, uint64_t batchBytes = 0) const
+	{
+		flush();
+		btlbf_fastx_stats st;
+		btlbf_shim::check(btlbf_contains_fastx(m_f, path.c_str(), perLine ? BTLBF_FASTX_LINES : BTLBF_FASTX_RECORDS,
+		                                       batchBytes, &st));
+		return st;
+	}
 	// contains() of every window: result[p] for window start p; valid[p] = window was a clean k-mer
 	void containsSeq(const std::string& seq, std::vector<bool>& result, std::vector<bool>& valid) const
 	{

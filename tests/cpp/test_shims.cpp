@@ -219,12 +219,50 @@ static void fused_path_equals_iterator_path(const char* golden_dir)
 	}
 }
 
+// file ingestion: the two reference loaders' semantics (one sequence per FASTA record / per line)
+static void file_loaders_equal_insert_seq()
+{
+	const std::string s1 = "GATTACAGATTACANNGATTACACCCGGGTTTAAACGTACGTTGCAAGCTTAGGCTAACGTAGCTAGCTAGGATCCGATC";
+	const std::string s2 = "ACGTTGCATGCATGCAAACCGGTTACGATCGATCGATTAGCTAGCTAGGCTAGCTA";
+	const unsigned h = 3, k = 21;
+	const std::string fa = tmp_name("fasta");
+	{
+		std::ofstream o(fa.c_str());
+		o << ">one\n" << s1.substr(0, 40) << "\n" << s1.substr(40) << "\n>two\n" << s2 << "\n";
+	}
+	BloomFilter rec(1 << 14, h, k), lin(1 << 14, h, k), a(1 << 14, h, k), b(1 << 14, h, k);
+	const btlbf_fastx_stats st = rec.insertFile(fa);
+	CHECK(st.n_records == 2 && st.n_bases == s1.size() + s2.size());
+	lin.insertFile(fa, true);
+	insertSeq(a, s1, h, k); // contigsToBloom: lines of a record concatenated
+	insertSeq(a, s2, h, k);
+	insertSeq(b, s1.substr(0, 40), h, k); // loadBf: every line by itself
+	insertSeq(b, s1.substr(40), h, k);
+	insertSeq(b, s2, h, k);
+	const std::string f1 = tmp_name("r"), f2 = tmp_name("a"), f3 = tmp_name("l"), f4 = tmp_name("b");
+	rec.storeFilter(f1);
+	a.storeFilter(f2);
+	lin.storeFilter(f3);
+	b.storeFilter(f4);
+	CHECK(slurp(f1) == slurp(f2));
+	CHECK(slurp(f3) == slurp(f4));
+	CHECK(slurp(f1) != slurp(f3));
+	const btlbf_fastx_stats q = rec.containsFile(fa);
+	CHECK(q.n_windows > 0 && q.n_hits == q.n_windows);
+	std::remove(fa.c_str());
+	std::remove(f1.c_str());
+	std::remove(f2.c_str());
+	std::remove(f3.c_str());
+	std::remove(f4.c_str());
+}
+
 int main(int argc, char** argv)
 {
 	bloom_basic();
 	hash_known_answers();
 	counting_basic();
 	fused_path_equals_iterator_path(argc > 1 ? argv[1] : nullptr);
+	file_loaders_equal_insert_seq();
 	if (g_fail) {
 		std::fprintf(stderr, "%d checks failed\n", g_fail);
 		return 1;
