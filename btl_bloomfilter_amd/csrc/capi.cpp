@@ -1054,13 +1054,19 @@ bool plan_splits(PartPlan& pl, uint32_t regions_in_total)
 		regions_in = o.regions;
 		++pl.n_levels;
 	}
-	// a single split level is run in groups of level-0 bins (split a group, apply its segments, next
-	// group): the level-1 arrays then hold one group instead of the whole batch, so a batch can be
-	// almost twice as large for the same scratch and the filter is swept fewer times
+	// the split levels and the apply pass run in groups of level-0 bins (split a group all the way
+	// down, apply its segments, next group): the arrays of the split levels then hold one group
+	// instead of the whole batch, so a batch can be almost twice as large for the same scratch and the
+	// filter is swept fewer times
 	pl.group_bins = 0;
-	if (pl.n_levels == 2 && pl.lv[0].bins >= 64) {
+	if (pl.n_levels >= 2 && pl.lv[0].bins >= 16) {
 		pl.group_bins = (pl.lv[0].bins + 7) / 8;
-		pl.lv[1].regions = std::max(1u, std::min(regions_in_total, (512 + pl.group_bins - 1) / pl.group_bins));
+		uint32_t bins_g = pl.group_bins, r_in = regions_in_total;
+		for (int j = 1; j < pl.n_levels; ++j) {
+			pl.lv[j].regions = std::max(1u, std::min(r_in, (512 + bins_g - 1) / bins_g));
+			r_in = pl.lv[j].regions;
+			bins_g *= pl.lv[j].P;
+		}
 	}
 	return true;
 }
@@ -1074,7 +1080,12 @@ void plan_caps(PartPlan& pl, double entries, int first_level)
 		// the last level has n_seg useful bins although bins may be rounded up
 		const double useful = j == pl.n_levels - 1 ? (double)std::min<uint64_t>(pl.n_seg, l.bins) : (double)l.bins;
 		l.cap = chunks_for(entries / (useful * l.regions), 1);
-		l.alloc_bins = j == 1 && pl.group_bins ? pl.group_bins * l.P : l.bins;
+		l.alloc_bins = l.bins;
+		if (j >= 1 && pl.group_bins) {
+			l.alloc_bins = pl.group_bins;
+			for (int i = 1; i <= j; ++i)
+				l.alloc_bins *= pl.lv[i].P;
+		}
 		l.cnt_bytes = ((uint64_t)l.alloc_bins * l.regions * 4 + 255) / 256 * 256;
 		l.ent_bytes = (uint64_t)l.alloc_bins * l.regions * l.cap * (kChunk * 4);
 		pl.bytes_total += l.cnt_bytes + l.ent_bytes;
@@ -1142,21 +1153,28 @@ int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, in
 {
 	const int prof_split = query ? BTLBF_PROF_QUERY_SPLIT : BTLBF_PROF_INSERT_SPLIT;
 	const int prof_apply = query ? BTLBF_PROF_QUERY_TEST : BTLBF_PROF_INSERT_APPLY;
-	if (pl.n_levels == 2 && pl.group_bins) {
-		// one split level, processed group by group
-		const PartLevel& l1 = pl.lv[1];
+	if (pl.n_levels >= 2 && pl.group_bins) {
+		// group by group: split the group's level-0 bins all the way down, then apply its segments
 		for (uint32_t b0 = 0; b0 < pl.lv[0].bins; b0 += pl.group_bins) {
-			const uint32_t nb = std::min(pl.group_bins, pl.lv[0].bins - b0);
-			{
+			PartIn in = in0;
+			uint32_t first_in = b0, abs_first = b0, n_in = std::min(pl.group_bins, pl.lv[0].bins - b0);
+			uint32_t in_shift = pl.lv[0].shift;
+			for (int j = 1; j < pl.n_levels; ++j) {
 				ProfSpan ps(f, prof_split, s);
-				HIP_TRY(launch_part_split(f->d_data, in0, b0, nb, l1.out(), l1.shift, pl.lv[0].shift, sd, query, s));
+				HIP_TRY(launch_part_split(f->d_data, in, first_in, abs_first, n_in, pl.lv[j].out(), pl.lv[j].shift,
+				                          in_shift, sd, query, s));
+				in = pl.lv[j].in();
+				first_in = 0;
+				abs_first *= pl.lv[j].P;
+				n_in *= pl.lv[j].P;
+				in_shift = pl.lv[j].shift;
 			}
-			const uint64_t seg_first = (uint64_t)b0 * l1.P;
+			const uint64_t seg_first = abs_first;
 			if (seg_first >= pl.n_seg)
 				break;
-			const uint64_t n_seg = std::min<uint64_t>((uint64_t)nb * l1.P, pl.n_seg - seg_first);
+			const uint64_t n_seg = std::min<uint64_t>(n_in, pl.n_seg - seg_first);
 			ProfSpan ps(f, prof_apply, s);
-			HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.seg_shift, seg_first, n_seg, l1.in(), sd, query, s));
+			HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.seg_shift, seg_first, n_seg, in, sd, query, s));
 		}
 		return BTLBF_OK;
 	}
@@ -1164,7 +1182,7 @@ int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, in
 	uint32_t bins_in = pl.lv[0].bins, in_shift = pl.lv[0].shift;
 	for (int j = 1; j < pl.n_levels; ++j) {
 		ProfSpan ps(f, prof_split, s);
-		HIP_TRY(launch_part_split(f->d_data, in, 0, bins_in, pl.lv[j].out(), pl.lv[j].shift, in_shift, sd, query, s));
+		HIP_TRY(launch_part_split(f->d_data, in, 0, 0, bins_in, pl.lv[j].out(), pl.lv[j].shift, in_shift, sd, query, s));
 		in = pl.lv[j].in();
 		bins_in = pl.lv[j].bins;
 		in_shift = pl.lv[j].shift;
@@ -1486,9 +1504,8 @@ extern "C" int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, 
 	sd.spill_list = spill_list;
 	sd.spill_count = reinterpret_cast<unsigned long long*>(spill_count);
 	sd.spill_cap = spill_cap;
-	HIP_TRY(hipMemsetAsync(spill_count, 0, 8, s));
-	if (counts)
-		HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
+	// spill_count and counts ACCUMULATE over the batches of a pass (the caller zeroes them once): no
+	// host round trip per batch, so the exchange of one batch can overlap the hashing of the next
 	if (a.n_tiles == 0) { // nothing to hash: still publish empty regions
 		HIP_TRY(hipMemsetAsync(send_cnt, 0, (size_t)rp.cnt_bytes_per_shard * n_shards, s));
 		return BTLBF_OK;

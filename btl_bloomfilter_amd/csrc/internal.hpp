@@ -166,8 +166,9 @@ uint32_t part_hash_lds_bytes(const HashParams& hp, uint32_t p0);
 bool part_hash_fits(const HashParams& hp, uint32_t p0);
 hipError_t launch_part_hash(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd, int query,
                             hipStream_t s);
-hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_bin, uint32_t n_in_bins, const PartOut& out,
-                             uint32_t sub_shift, uint32_t in_shift, const PartSide& sd, int query, hipStream_t s);
+hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_in, uint32_t abs_first, uint32_t n_in_bins,
+                             const PartOut& out, uint32_t sub_shift, uint32_t in_shift, const PartSide& sd, int query,
+                             hipStream_t s);
 hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_shift, uint64_t seg_first, uint64_t n_seg,
                              const PartIn& in, const PartSide& sd, int query, hipStream_t s);
 hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t* table, uint64_t mask, hipStream_t s);

@@ -36,27 +36,28 @@ __device__ __forceinline__ uint32_t part_in_region(const PartIn& in, uint32_t b,
 // workgroup (b, g): blockIdx.x = b * slices + g.  It consumes input regions g, g+slices, ... of input
 // bin b and writes region g of every sub-bin b*P + sub, sub = entry >> sub_shift; the new entry is
 // the low sub_shift bits.  in_shift = log2(positions per input bin), for the overflow path.
-// Only input bins [first_bin, first_bin + gridDim.x/slices) are processed (a GROUP of bins: the output
-// arrays hold one group at a time, which keeps the level-1 scratch small); output bins are numbered
-// relative to the group.
+// One GROUP of input bins per launch: bins [first_in, first_in + gridDim.x/slices) of the input arrays;
+// the output arrays hold one group at a time (bins numbered relative to the group), which keeps the
+// scratch of the split levels small.  Input bin i is bin i + abs_off of its level in absolute terms
+// (the input arrays themselves are group-relative from the second split level on).
 template <bool QUERY>
 __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, const PartIn in, const PartOut out,
                                                                  const uint32_t slices, const uint32_t sub_shift,
-                                                                 const uint32_t in_shift, const uint32_t first_bin,
-                                                                 const PartSide sd)
+                                                                 const uint32_t in_shift, const uint32_t first_in,
+                                                                 const uint32_t abs_off, const PartSide sd)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	const uint32_t tid = threadIdx.x;
-	const uint32_t b = first_bin + blockIdx.x / slices, g = blockIdx.x % slices;
+	const uint32_t b = first_in + blockIdx.x / slices, g = blockIdx.x % slices;
 	const PartLds pl = part_carve(dyn, out.P);
 	part_init<kPartThreads>(pl, out.P);
 	uint32_t* words = static_cast<uint32_t*>(filter);
 	const uint32_t sub_mask = (1u << sub_shift) - 1;
-	const uint64_t bin_base = (uint64_t)b << in_shift;
+	const uint64_t bin_base = (uint64_t)(b + abs_off) << in_shift;
 	auto ovf = [&](uint32_t sub, uint32_t v) {
 		part_direct<QUERY>(words, sd, bin_base | ((uint64_t)sub << sub_shift) | v);
 	};
-	const uint32_t bin0 = (b - first_bin) * out.P;
+	const uint32_t bin0 = (b - first_in) * out.P;
 	const uint32_t n_regions_in = in.blocks * in.regions_per_block;
 	constexpr int kVec = 4; // uint4 loads per thread per round -> 16 entries
 	STAMP_DECL;
@@ -305,8 +306,9 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bi
 	return launch_hash_any(a, out, bin_shift, sd, dyn, query, s);
 }
 
-hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_bin, uint32_t n_in_bins, const PartOut& out,
-                             uint32_t sub_shift, uint32_t in_shift, const PartSide& sd, int query, hipStream_t s)
+hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_in, uint32_t abs_first, uint32_t n_in_bins,
+                             const PartOut& out, uint32_t sub_shift, uint32_t in_shift, const PartSide& sd, int query,
+                             hipStream_t s)
 {
 	if (n_in_bins == 0)
 		return hipSuccess;
@@ -320,10 +322,10 @@ hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_bin,
 	const dim3 grid(n_in_bins * slices);
 	if (query)
 		hipLaunchKernelGGL(part_split_kernel<true>, grid, dim3(kPartThreads), dyn, s, filter, in, out, slices,
-		                   sub_shift, in_shift, first_bin, sd);
+		                   sub_shift, in_shift, first_in, abs_first - first_in, sd);
 	else
 		hipLaunchKernelGGL(part_split_kernel<false>, grid, dim3(kPartThreads), dyn, s, filter, in, out, slices,
-		                   sub_shift, in_shift, first_bin, sd);
+		                   sub_shift, in_shift, first_in, abs_first - first_in, sd);
 	return hipGetLastError();
 }
 

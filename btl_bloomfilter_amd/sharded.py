@@ -154,7 +154,7 @@ class HipShardOps:
 
 class ShardedBloomFilter:
     def __init__(self, global_bits, hash_num, kmer_size, device=0, group=None, ops=None, batch_reads=2_000_000,
-                 slack=1.25, route=True, batch_bytes_cap=0):
+                 slack=1.25, route=True, batch_bytes_cap=0, pipeline=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -169,6 +169,10 @@ class ShardedBloomFilter:
         self.slack = slack
         self.route_enabled = route         # use the partitioned routing path when the geometry allows
         self.batch_bytes_cap = batch_bytes_cap
+        # routed path: keep the exchange of batch i in flight while batch i+1 is routed (two buffer
+        # sets).  None = whenever the exchange is asynchronous (RCCL); True forces the same schedule
+        # over a synchronous exchange (tests).
+        self.pipeline = pipeline
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         # gloo moves host memory: stage device tensors through the CPU (test mode only)
         self.stage_cpu = backend == "gloo"
@@ -265,14 +269,18 @@ class ShardedBloomFilter:
         dist.all_gather(outs, pad, group=self.group)
         return torch.cat([o[:c] for o, c in zip(outs, cnts)]).to(dev)
 
-    def _route_batch_bytes(self, reads, read_len):
-        """bytes of read buffer per batch (same on every rank): four block-sets must fit in free HBM"""
+    def _route_batch_bytes(self, reads, read_len, n_slots=1):
+        """bytes of read buffer per batch (same on every rank): the send and receive block sets (n_slots
+        of each) and two split levels must fit in free HBM"""
         longest = self._max_over_ranks(reads.numel())
         if longest == 0:
             return 0, 0
         free = torch.cuda.mem_get_info(self.ops.device)[0] if self.ops.device.type == "cuda" else 1 << 40
-        # per read byte: h*(L-k+1)/L probes * 4 B per entry, ~1.1x capacity, send + recv + two split levels
-        per_byte = self.h * max(read_len - self.k + 1, 1) / read_len * 4 * 1.1 * 4.2
+        free = -self._max_over_ranks(-free)  # the smallest over ranks: every rank must plan the same batch
+        # per read byte: h*(L-k+1)/L probes * 4 B per entry, ~1.1x capacity; block sets: send (+ receive
+        # when there are peers), n_slots of each, + the owner's split levels, which hold 1/8 of a batch
+        sets = n_slots * (2 if self.world > 1 else 1) + 0.4
+        per_byte = self.h * max(read_len - self.k + 1, 1) / read_len * 4 * 1.1 * sets
         batch = int(0.7 * free / per_byte) // (64 * read_len) * (64 * read_len)
         batch = max(batch, 64 * read_len)
         if self.batch_bytes_cap:
@@ -280,57 +288,92 @@ class ShardedBloomFilter:
         batch = min(batch, -(-longest // (64 * read_len)) * (64 * read_len))
         return batch, -(-longest // batch)
 
+    def _exchange_start(self, send, recv):
+        """fixed-size all-to-all of a uint8 block set.  RCCL: asynchronous on the communicator's stream
+        (returns the work handle; the compute stream goes on with the next batch); gloo (test mode):
+        synchronous through host memory; one rank: recv is send."""
+        if self.world == 1:
+            return None
+        if self.stage_cpu:
+            recv.copy_(self._fixed_all_to_all(send))
+            return None
+        wide = send.numel() % (8 * self.world) == 0  # 8-byte elements keep per-peer counts below 2^31
+        a, b = (recv.view(torch.int64), send.view(torch.int64)) if wide else (recv, send)
+        return dist.all_to_all_single(a, b, group=self.group, async_op=True)
+
     def _routed_pass(self, reads, read_len, query, hit_bits=None, counts=None):
+        """One insert / query pass over this rank's reads on the routed path.  Per batch: route (pass A
+        with the global geometry) -> fixed-size all-to-all -> apply at the owners.  With RCCL the
+        exchange of batch i runs while batch i+1 is routed and batch i-1 applied (two buffer sets);
+        nothing in the loop waits on the host.  Spill and fail lists accumulate over the pass and are
+        dealt with once at its end."""
         ops, W, dev = self.ops, self.world, self.ops.device
-        batch, n_batches = self._route_batch_bytes(reads, read_len)
+        pipelined = W > 1 and (not self.stage_cpu if self.pipeline is None else bool(self.pipeline))
+        batch, n_batches = self._route_batch_bytes(reads, read_len, 2 if pipelined else 1)
         if n_batches == 0:
             return True
         ent_b, cnt_b = ops.route_plan(batch, read_len)
-        send_ent = torch.empty(W * ent_b, dtype=torch.uint8, device=dev)
-        send_cnt = torch.empty(W * cnt_b, dtype=torch.uint8, device=dev)
+        n_slots = 2 if pipelined else 1
+        send_ent = [torch.empty(W * ent_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
+        send_cnt = [torch.empty(W * cnt_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
+        if W > 1:
+            recv_ent = [torch.empty_like(t) for t in send_ent]
+            recv_cnt = [torch.empty_like(t) for t in send_cnt]
+        else:
+            recv_ent, recv_cnt = send_ent, send_cnt
         spill = torch.empty(self.SPILL_CAP, dtype=torch.int64, device=dev)
         spill_count = torch.zeros(1, dtype=torch.int64, device=dev)
         fail = torch.empty(self.FAIL_CAP, dtype=torch.int64, device=dev) if query else None
         fail_count = torch.zeros(1, dtype=torch.int64, device=dev) if query else None
         cnt2 = torch.zeros(2, dtype=torch.int64, device=dev) if query else None
-        n_valid = n_hit = 0
+
+        def finish(p):
+            slot, works = p
+            for w in works:
+                if w is not None:
+                    w.wait()  # RCCL: the compute stream waits, the host does not
+            ops.apply_routed(recv_ent[slot], recv_cnt[slot], W, batch, read_len, query, fail, fail_count)
+
+        pending = None
         for bi in range(n_batches):
+            slot = bi % n_slots
             off = bi * batch
-            chunk = reads[off: off + batch]
+            chunk = reads[off: off + batch]  # empty once this rank has run out of reads: it still takes part
             view = None
             if query:
                 w0, words = off // 64, (chunk.numel() + 63) // 64
                 view = hit_bits[w0: w0 + words]
-                fail_count.zero_()
-            if chunk.numel() == 0:  # this rank has run out of reads but still takes part in the exchange
-                chunk = reads[:0]
-            ops.route(chunk, read_len, batch, query, send_ent, send_cnt, view, None, cnt2, spill, spill_count)
-            recv_ent = self._fixed_all_to_all(send_ent)
-            recv_cnt = self._fixed_all_to_all(send_cnt)
-            ops.apply_routed(recv_ent, recv_cnt, W, batch, read_len, query, fail, fail_count)
-            # entries that could not be staged at their origin travel as explicit positions (rare)
-            n_spill = min(int(spill_count.item()), self.SPILL_CAP)
-            if int(spill_count.item()) > self.SPILL_CAP:
+            ops.route(chunk, read_len, batch, query, send_ent[slot], send_cnt[slot], view, None, cnt2, spill,
+                      spill_count)
+            works = (self._exchange_start(send_ent[slot], recv_ent[slot]),
+                     self._exchange_start(send_cnt[slot], recv_cnt[slot]))
+            if pipelined:
+                if pending is not None:
+                    finish(pending)
+                pending = (slot, works)
+            else:
+                finish((slot, works))
+        if pending is not None:
+            finish(pending)
+        # entries that could not be staged at their origin travel as explicit positions (rare)
+        n_spill = int(spill_count.item())
+        if self._max_over_ranks(1 if n_spill > self.SPILL_CAP else 0):
+            return False
+        gathered = self._all_gather_var(spill, n_spill)
+        if gathered.numel():
+            ops.apply_spill(gathered, query, fail, fail_count)
+        if query:
+            n_fail = int(fail_count.item())
+            if self._max_over_ranks(1 if n_fail > self.FAIL_CAP else 0):
+                return False  # miss-heavy: the caller redoes the query on the direct path
+            fails = self._all_gather_var(fail, n_fail)
+            if fails.numel() > self.FAIL_CAP:
                 return False
-            gathered = self._all_gather_var(spill, n_spill)
-            if gathered.numel():
-                ops.apply_spill(gathered, query, fail, fail_count)
-            if query:
-                n_fail = int(fail_count.item())
-                over = self._max_over_ranks(1 if n_fail > self.FAIL_CAP else 0)
-                if over:
-                    return False  # a miss-heavy batch: the caller redoes the query on the direct path
-                fails = self._all_gather_var(fail, n_fail)
-                if fails.numel() > self.FAIL_CAP:
-                    return False
-                if fails.numel() and chunk.numel():
-                    ops.resolve(chunk, read_len, fails, view)
-                if counts is not None and chunk.numel():
-                    n_valid += int(cnt2[0].item())
-                    n_hit += ops.popcount_bits(view)
-        if query and counts is not None:
-            counts[0] = n_valid
-            counts[1] = n_hit
+            if fails.numel() and reads.numel():
+                ops.resolve(reads, read_len, fails, hit_bits)
+            if counts is not None:
+                counts[0] = int(cnt2[0].item())
+                counts[1] = ops.popcount_bits(hit_bits[: (reads.numel() + 63) // 64]) if reads.numel() else 0
         return True
 
     def insert_reads(self, reads, read_len):

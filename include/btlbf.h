@@ -242,8 +242,10 @@ int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, 
  *  route_seqs : origin.  Hash the buffer and partition every probe position into the 1024 bins:
  *               send_ent / send_cnt receive n_shards consecutive blocks (block g goes to shard g).
  *               query != 0 additionally writes valid_bits and initialises hit_bits = valid_bits;
- *               counts[0] (optional) = clean windows.  Entries that cannot be staged are appended to
- *               spill_list as global positions (spill_count is zeroed by the call).
+ *               counts[0] (optional) += clean windows.  Entries that cannot be staged are appended to
+ *               spill_list as global positions.  counts and spill_count ACCUMULATE over calls (zero
+ *               them once per pass): no host round trip per batch is needed, so the exchange of one
+ *               batch can overlap the hashing of the next.
  *  apply_routed: owner.  recv_ent / recv_cnt hold n_blocks blocks (one per origin, any order); they are
  *               split down to segments and ORed into (query == 0) or tested against (query != 0) this
  *               shard in LDS.  Positions found clear are appended to fail_list as GLOBAL positions

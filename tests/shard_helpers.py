@@ -132,7 +132,7 @@ def gpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
     dist.destroy_process_group()
 
 
-def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, route_bins=0):
+def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, route_bins=0, pipeline=None):
     """the routed (partitioned) multi-GPU path with the real HIP kernels, all ranks on cuda:0"""
     if route_bins:
         os.environ["BTLBF_ROUTE_BINS"] = str(route_bins)
@@ -141,7 +141,8 @@ def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, 
 
     torch.cuda.set_device(0)
     _init(rank, world, port)
-    f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=4 << 20)  # several batches
+    # several batches; pipeline=True runs the double-buffered schedule of the RCCL path over gloo
+    f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=4 << 20, pipeline=pipeline)
     assert f._routed()
     mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
     f.insert_reads(mine, read_len)

@@ -87,14 +87,18 @@ def test_sharded_hip_two_ranks_one_gpu(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_sharded_routed_partitioned_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("pipeline", [None, True])
+def test_sharded_routed_partitioned_two_ranks_one_gpu(tmp_path, pipeline):
     """routed path: pass A per origin, fixed-size exchange of 4-byte entries, owner splits + LDS apply;
     queries return only failed positions.  Checked against the reference's golden digest and against
     the single-GPU direct kernels (all-hit, few-miss and miss-heavy queries)."""
     g = load_golden("digests.json")["bf_medium"]  # 200000 reads, 2^30 bits, k=31, h=4
     bits, h, k, L, world = g["bits"], g["h"], g["k"], g["read_len"], 2
     n_reads = g["n_reads"] // world
-    mp.spawn(gpu_worker_routed, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L), nprocs=world, join=True)
+    # pipeline=True: the schedule of the RCCL path (exchange of batch i in flight while batch i+1 is
+    # routed, two buffer sets, deferred apply) over the synchronous test exchange
+    mp.spawn(gpu_worker_routed, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L, 0, pipeline),
+             nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
     assert sha(got) == g["body_sha256"]
     for rank in range(world):
