@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 		// registers across it)
 		uint32_t bin[kPartHalf * H], val[kPartHalf * H];
 		uint32_t vmask = 0, live = 0;
-		seq_lane_windows<SPACED, kPartW>(tile, sh, a.hp, spaced_lds, tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
+		seq_lane_windows<SPACED, kPartW, H>(tile, sh, a.hp, spaced_lds, tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
 			vmask |= (uint32_t)ok << w;
 			const int w4 = w % kPartHalf;
 			if (w4 == 0)

@@ -248,7 +248,9 @@ __device__ __forceinline__ U64x2 tab16(const void* base, uint32_t byte_off)
 
 // Walk the lane's KW consecutive windows (first base at LDS index li0) and call
 // f(w, clean, const WinHash<SPACED>&) for each.
-template <bool SPACED, int KW = kW, class F>
+// HS > 0: the number of hashes per window (n_seeds * h2) is known at compile time, so the spaced-seed
+// hash values stay in registers (statically indexed); HS = 0: any count, array indexed at run time.
+template <bool SPACED, int KW = kW, int HS = 0, class F>
 __device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqShared& sh, const HashParams& hp,
                                                  const uint8_t* spaced_lds, uint32_t li0, F&& f)
 {
@@ -324,7 +326,7 @@ __device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqS
 		wh.bcan = rh < fh ? rh : fh;
 		if (SPACED) {
 			const uint32_t h2 = hp.h2;
-			for (uint32_t j = 0; j < hp.n_seeds; ++j) {
+			auto seed_base = [&](uint32_t j, bool& rev) {
 				uint64_t fs = fh, rs = rh;
 				for (uint32_t d = hp.dc_off[j]; d < hp.dc_off[j + 1]; ++d) {
 					const uint32_t di = dc_idx[d];
@@ -332,14 +334,38 @@ __device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqS
 					fs ^= tt.x;
 					rs ^= tt.y;
 				}
-				const bool s = rs < fs;
-				const uint64_t b = s ? rs : fs;
-				wh.hv[SPACED ? j * h2 : 0] = b;
-				for (uint32_t j2 = 1; j2 < h2; ++j2)
-					wh.hv[SPACED ? j * h2 + j2 : 0] = extra_hash(b, hp.kms, j2);
-				if (s)
-					for (uint32_t j2 = 0; j2 < h2; ++j2)
-						wh.stn |= 1u << (j * h2 + j2); // h <= 32 here
+				rev = rs < fs;
+				return rev ? rs : fs;
+			};
+			if (HS > 0) {
+				// hash idx = seed j, extra hash j2 with idx = j*h2 + j2: (j, j2) are tracked as uniform
+				// counters so that idx -- the array index -- is a compile-time constant
+				uint32_t j = 0, j2 = 0;
+				uint64_t b = 0;
+				bool rev = false;
+#pragma unroll
+				for (int idx = 0; idx < (HS > 0 ? HS : 1); ++idx) {
+					if (j2 == 0)
+						b = seed_base(j, rev);
+					wh.hv[SPACED ? idx : 0] = j2 ? extra_hash(b, hp.kms, j2) : b;
+					if (rev)
+						wh.stn |= 1u << idx;
+					if (++j2 == h2) {
+						j2 = 0;
+						++j;
+					}
+				}
+			} else {
+				for (uint32_t j = 0; j < hp.n_seeds; ++j) {
+					bool rev;
+					const uint64_t b = seed_base(j, rev);
+					wh.hv[SPACED ? j * h2 : 0] = b;
+					for (uint32_t j2 = 1; j2 < h2; ++j2)
+						wh.hv[SPACED ? j * h2 + j2 : 0] = extra_hash(b, hp.kms, j2);
+					if (rev)
+						for (uint32_t j2 = 0; j2 < h2; ++j2)
+							wh.stn |= 1u << (j * h2 + j2); // h <= 32 here
+				}
 			}
 		}
 		f(w, ok, wh);
