@@ -445,7 +445,7 @@ def test_partitioned_insert_golden_digests(bf, name):
 
 
 @pytest.mark.parametrize("bits,k,h", [(1000, 5, 4), (1 << 19, 31, 1), ((1 << 19) + 64, 31, 3), (3 << 29, 25, 5),
-                                      (1 << 31, 64, 2)])
+                                      (1 << 31, 64, 2), (1 << 28, 25, 8), (1 << 27, 150, 7), (5 << 20, 1, 6)])
 def test_partitioned_equals_direct_odd_shapes(bf, oracle, bits, k, h):
     import torch
 
@@ -491,6 +491,33 @@ def test_partitioned_small_scratch_many_batches_and_skew(bf):
     torch.cuda.synchronize()
     assert a.getPop() == b.getPop()
     assert hashlib.sha256(a.download()).hexdigest() == hashlib.sha256(b.download()).hexdigest()
+
+
+@pytest.mark.parametrize("n_seeds,h2", [(2, 2), (3, 1), (4, 2), (1, 5)])
+def test_partitioned_spaced_seed_shapes(bf, n_seeds, h2):
+    """seeds x extra hashes per seed in the partitioned pass (hash values indexed statically there)
+    against the direct kernel, insert and query"""
+    import torch
+
+    seeds = ["1110111011101110111011101110111", "1101101101101101011011011011011",
+             "1111001111001111111001111001111", "1011101011101011101011101011101"][:n_seeds]
+    bits, L, h = 1 << 30, 150, n_seeds * h2
+    reads = bf.synth_reads_device(9, 0, 40000, L)
+    reads[1000:1010] = ord("N")
+    a, b = bf.BloomFilter(bits, h, 31), bf.BloomFilter(bits, h, 31)
+    for f, mode in ((a, "direct"), (b, "partitioned")):
+        f.setSpacedSeeds(seeds, h2)
+        f.setInsertMode(mode)
+        f.setQueryMode(mode)
+        f.insertSeqs(reads, read_len=L)
+    torch.cuda.synchronize()
+    assert a.getPop() == b.getPop() > 0
+    assert (a.download() == b.download()).all()
+    q = torch.cat([reads[: 5000 * L], bf.synth_reads_device(10, 0, 20, L)])
+    ha, _, ca = a.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    hb, _, cb = b.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    torch.cuda.synchronize()
+    assert ca.tolist() == cb.tolist() and bool((ha == hb).all().item())
 
 
 def test_partitioned_spaced_seeds_and_shard(bf):
