@@ -23,7 +23,8 @@ struct PartLds {
 	uint32_t* pt;      // [P] low 16 bits: entries in the ring (+ offered this round); high 16: ring write position
 	uint32_t* fl;      // [P] entries flushed from the bin this round (multiple of 32)
 	uint32_t* written; // [P] chunks written to this workgroup's region of the bin
-	uint16_t* flist;   // [kFlushItems] flush items, a private slice per wave: bin | chunk of this round's flush << 10
+	uint16_t* flist;   // [kFlushItems] flush items, a private slice per wave: bin | ring chunk << 10 ...
+	uint32_t* fwc;     // [kFlushItems] ... and the chunk's index inside the region (0xffffffff: over capacity)
 	uint32_t sc_shift; // log2(SC)
 };
 
@@ -37,7 +38,7 @@ __host__ __device__ inline uint32_t part_pow2ceil(uint32_t x)
 
 __host__ __device__ inline uint32_t part_lds_bytes(uint32_t P)
 {
-	return kStageEntries * 4 + 3 * P * 4 + kFlushItems * 2 + 16;
+	return kStageEntries * 4 + 3 * P * 4 + kFlushItems * 6 + 16;
 }
 
 __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
@@ -47,7 +48,8 @@ __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
 	l.pt = l.stage + kStageEntries;
 	l.fl = l.pt + P;
 	l.written = l.fl + P;
-	l.flist = reinterpret_cast<uint16_t*>(l.written + P);
+	l.fwc = l.written + P;
+	l.flist = reinterpret_cast<uint16_t*>(l.fwc + kFlushItems);
 	uint32_t pc = part_pow2ceil(P < 32 ? 32 : P), sh = 0;
 	while ((kStageEntries >> sh) > pc)
 		++sh; // kStageEntries / 2^sh == pc  ->  SC = 2^sh
@@ -149,7 +151,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 		// bins are owned by lanes (P <= NT): wave v owns bins [64v, 64v+64) and flushes them itself,
 		// through its private slice of the flush list -- no workgroup barrier in between
 		const uint32_t b = tid, lane = tid & 63;
-		uint32_t nfl = 0;
+		uint32_t nfl = 0, rd0 = 0, w0 = 0;
 		if (b < P) {
 			const uint32_t w = l.pt[b];
 			const uint32_t occ = w & 0xffffu;           // ring content + everything offered this round
@@ -161,38 +163,34 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 			const uint32_t nocc = tot < SC ? tot : SC;
 			l.pt[b] = (((w >> 16) - (tot - nocc)) << 16) | nocc;
 			l.fl[b] = f;
-			if (nfl)
-				l.written[b] += nfl;
+			if (nfl) {
+				w0 = l.written[b];
+				l.written[b] = w0 + nfl;
+				rd0 = ((w >> 16) - occ) & ring; // read position of the ring: both halves of pt grew alike
+			}
 		}
 		// inclusive prefix sum of nfl over the wave (DPP row shifts + row broadcasts, no LDS) -> slots
 		// in the wave's slice (64 bins * SC/kChunk items)
 		const uint32_t incl = wave_scan_incl(nfl);
 		const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
 		const uint32_t slice = (tid >> 6) * ((64u / kChunk) << l.sc_shift);
-		for (uint32_t c = 0; c < nfl; ++c)
-			l.flist[slice + incl - nfl + c] = (uint16_t)(b | (c << 10));
+		for (uint32_t c = 0; c < nfl; ++c) {
+			const uint32_t j = slice + incl - nfl + c;
+			l.flist[j] = (uint16_t)(b | ((((rd0 >> kChunkShift) + c) & (ring >> kChunkShift)) << 10));
+			l.fwc[j] = w0 + c < o.cap ? w0 + c : 0xffffffffu;
+		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		// kChunk/4 lanes per chunk, 16 bytes per lane -> one aligned line per chunk.  Where the chunk
-		// sits in the ring and in the region follows from the bin's (already updated) state:
-		//   ring read position before the flush = new write position - new occupancy - flushed
-		//   chunks written before the flush     = written - flushed chunks
+		// kChunk/4 lanes per chunk, 16 bytes per lane -> one aligned line per chunk
 		constexpr uint32_t kLanesPerChunk = kChunk / 4;
 		const uint32_t l4 = lane & (kLanesPerChunk - 1);
-		auto item = [&](uint32_t j, uint32_t& fb, uint32_t& src, uint64_t& dst, bool& fits) {
-			const uint32_t it = l.flist[slice + j];
-			fb = it & 1023;
-			const uint32_t c = it >> 10;
-			const uint32_t w = l.pt[fb], f = l.fl[fb];
-			const uint32_t rd = ((w >> 16) - (w & 0xffffu) - f + (c << kChunkShift)) & ring;
-			const uint32_t wc = l.written[fb] - (f >> kChunkShift) + c;
-			src = (fb << l.sc_shift) + rd + l4 * 4;
-			fits = wc < o.cap;
-			dst = ((uint64_t)((bin0 + fb) * o.regions + region) * o.cap + wc) * kChunk + l4 * 4;
-		};
-		auto emit = [&](uint32_t fb, const uint4& v, uint64_t dst, bool fits) {
-			if (fits) {
+		for (uint32_t j = lane / kLanesPerChunk; j < total; j += 64 / kLanesPerChunk) {
+			const uint32_t it = l.flist[slice + j], wc = l.fwc[slice + j];
+			const uint32_t fb = it & 1023, rc = it >> 10;
+			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(fb << l.sc_shift) + (rc << kChunkShift) + l4 * 4]);
+			if (wc != 0xffffffffu) {
+				const uint64_t dst = ((uint64_t)((bin0 + fb) * o.regions + region) * o.cap + wc) * kChunk + l4 * 4;
 				*reinterpret_cast<uint4*>(&o.ent[dst]) = v;
 			} else {
 				ovf(fb, v.x);
@@ -200,13 +198,6 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 				ovf(fb, v.z);
 				ovf(fb, v.w);
 			}
-		};
-		for (uint32_t j = lane / kLanesPerChunk; j < total; j += 64 / kLanesPerChunk) {
-			uint32_t fb, src;
-			uint64_t dst;
-			bool fits;
-			item(j, fb, src, dst, fits);
-			emit(fb, *reinterpret_cast<const uint4*>(&l.stage[src]), dst, fits);
 		}
 	}
 	__syncthreads();
