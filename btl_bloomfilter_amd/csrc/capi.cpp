@@ -1026,9 +1026,18 @@ unsigned ceil_log2(uint64_t x)
 
 bool plan_segments(uint64_t mloc, PartPlan& pl)
 {
+	// 64 KiB segments (two pass-C workgroups per CU) as long as they number at most 2^19, else 128 KiB:
+	// with more than 512 x 1024 segments pass A would need 1024 level-0 bins, whose 32-entry rings make
+	// a quarter of the entries take the late path (measured: pass A 63 -> 54 ms at 512 bins; the
+	// read-only pass C loses 0.7 ms per launch with one workgroup per CU)
 	pl.seg_shift = 19;
-	if (((mloc + (1ull << 19) - 1) >> 19) > 1024ull * 1024)
+	if (((mloc + (1ull << 19) - 1) >> 19) > 512ull * 1024)
 		pl.seg_shift = 20;
+	if (const char* e = getenv("BTLBF_SEG_SHIFT")) { // tuning knob: 19 or 20
+		const int v = atoi(e);
+		if (v == 19 || v == 20)
+			pl.seg_shift = (uint32_t)v;
+	}
 	pl.n_seg = (mloc + (1ull << pl.seg_shift) - 1) >> pl.seg_shift;
 	return pl.n_seg <= 1024ull * 1024;
 }
@@ -1223,7 +1232,12 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, Par
 		l0.bins = (uint32_t)pl.n_seg;
 		l0.shift = pl.seg_shift;
 	} else { // split the segment index bits evenly between pass A and pass B
-		const unsigned b1 = ceil_log2(pl.n_seg) / 2;
+		unsigned b1 = (ceil_log2(pl.n_seg) + 1) / 2; // pass B takes the larger half: pass A gains more from big rings
+		if (const char* e = getenv("BTLBF_SPLIT_BITS")) { // tuning knob: segment-index bits left to pass B
+			const int v = atoi(e);
+			if (v >= 1 && v <= 10 && ceil_log2(pl.n_seg) - v <= 10)
+				b1 = (unsigned)v;
+		}
 		l0.shift = pl.seg_shift + b1;
 		l0.bins = (uint32_t)((pl.n_seg + (1ull << b1) - 1) >> b1);
 	}

@@ -12,7 +12,6 @@ static constexpr int kPartThreads = 1024;
 static constexpr int kPartW = 8;                        // windows per lane and tile in pass A ...
 static constexpr int kPartHalf = 4;                     // ... partitioned in two rounds of 4 (the rings hold one)
 static constexpr int kPartTile = kPartThreads * kPartW; // windows per tile of pass A
-static constexpr int kApplyThreads = 512;
 static constexpr uint32_t kStageEntries = 32768; // LDS staging: 128 KiB of uint32 entries
 static constexpr uint32_t kFlushItems = kStageEntries / kChunk; // chunks the rings can hold = most one round flushes
 static constexpr uint32_t kPartLdsBudget = 160 * 1024 - 1536; // dynamic LDS a workgroup may ask for (static: SeqShared)

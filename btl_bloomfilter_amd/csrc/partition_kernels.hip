@@ -116,8 +116,10 @@ __device__ __forceinline__ void apply_entry(uint32_t* lds, uint32_t e, const Par
 // Memory-level parallelism is what this kernel lives on (two workgroups per CU): the segment is
 // fetched with 8 independent 16-byte loads per thread, and the entries of ALL regions are walked as
 // one virtual array with 4 independent loads per thread in flight.
-template <bool QUERY>
-__global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
+// NT = 512 for 64 KiB segments (two workgroups per CU), 1024 for 128 KiB segments (one per CU: twice
+// the loads in flight per workgroup make up for the missing second one)
+template <bool QUERY, int NT>
+__global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
                                                                  uint32_t seg_shift, uint32_t seg_first,
                                                                  const PartIn in, const PartSide sd)
 {
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 		any = 0;
 	__syncthreads();
 	uint32_t mine = 0;
-	for (uint32_t r = tid; r < n_regions; r += kApplyThreads) {
+	for (uint32_t r = tid; r < n_regions; r += NT) {
 		const uint32_t reg = part_in_region(in, ibin, r);
 		uint32_t n = in.cnt[reg];
 		if (n > cap_entries)
@@ -161,29 +163,13 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 	uint4* lds4 = reinterpret_cast<uint4*>(dyn);
 	uint4* g4 = reinterpret_cast<uint4*>(filter + byte0);
 	constexpr int kSegU = 8;
-	for (uint32_t base = 0; base < n_vec; base += kApplyThreads * kSegU) {
-		uint4 v[kSegU];
-#pragma unroll
-		for (int u = 0; u < kSegU; ++u) {
-			const uint32_t i = base + (uint32_t)u * kApplyThreads + tid;
-			v[u] = make_uint4(0, 0, 0, 0);
-			if (i < n_vec)
-				v[u] = g4[i];
-		}
-#pragma unroll
-		for (int u = 0; u < kSegU; ++u) {
-			const uint32_t i = base + (uint32_t)u * kApplyThreads + tid;
-			if (i < n_vec)
-				lds4[i] = v[u];
-		}
-	}
-	__syncthreads();
-	uint32_t* lds = reinterpret_cast<uint32_t*>(dyn);
-	if (tabled) {
-		// kEntU walkers per thread over the virtual concatenation of the regions' vectors
-		constexpr int kEntU = 4;
-		uint32_t wr[kEntU], wi[kEntU];
-		// move walker (r, i) forward to the region that holds its virtual vector index
+	constexpr int kEntU = 4;
+	// kEntU walkers per thread over the virtual concatenation of the regions' vectors; the first batch
+	// of entry loads is issued BEFORE the segment is waited for, and from then on the next batch is
+	// always in flight while the current one is applied
+	uint32_t wr[kEntU], wi[kEntU];
+	uint4 q[kEntU];
+	bool on[kEntU];
 #define BTLBF_SETTLE(r, i)                               \
 	while ((r) < n_regions) {                            \
 		const uint32_t nev__ = r_nev[(r)];               \
@@ -192,21 +178,49 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 		(i) -= nev__;                                    \
 		++(r);                                           \
 	}
+#define BTLBF_FETCH(dst, flag, u)                                                                              \
+	do {                                                                                                       \
+		flag = wr[u] < n_regions;                                                                              \
+		dst = make_uint4(0, 0, 0, 0);                                                                          \
+		if (flag)                                                                                              \
+			dst = reinterpret_cast<const uint4*>(in.ent + (uint64_t)r_reg[wr[u]] * cap_entries)[wi[u]];        \
+	} while (0)
+	if (tabled) {
 #pragma unroll
 		for (int u = 0; u < kEntU; ++u) {
 			wr[u] = 0;
-			wi[u] = (uint32_t)u * kApplyThreads + tid;
+			wi[u] = (uint32_t)u * NT + tid;
 			BTLBF_SETTLE(wr[u], wi[u])
+			BTLBF_FETCH(q[u], on[u], u);
 		}
-		while (wr[0] < n_regions) {
-			uint4 q[kEntU];
-			bool on[kEntU];
+	}
+	for (uint32_t base = 0; base < n_vec; base += NT * kSegU) {
+		uint4 v[kSegU];
+#pragma unroll
+		for (int u = 0; u < kSegU; ++u) {
+			const uint32_t i = base + (uint32_t)u * NT + tid;
+			v[u] = make_uint4(0, 0, 0, 0);
+			if (i < n_vec)
+				v[u] = g4[i];
+		}
+#pragma unroll
+		for (int u = 0; u < kSegU; ++u) {
+			const uint32_t i = base + (uint32_t)u * NT + tid;
+			if (i < n_vec)
+				lds4[i] = v[u];
+		}
+	}
+	__syncthreads();
+	uint32_t* lds = reinterpret_cast<uint32_t*>(dyn);
+	if (tabled) {
+		while (on[0]) {
+			uint4 nq[kEntU];
+			bool non[kEntU];
 #pragma unroll
 			for (int u = 0; u < kEntU; ++u) {
-				on[u] = wr[u] < n_regions;
-				q[u] = make_uint4(0, 0, 0, 0);
-				if (on[u])
-					q[u] = reinterpret_cast<const uint4*>(in.ent + (uint64_t)r_reg[wr[u]] * cap_entries)[wi[u]];
+				wi[u] += kEntU * NT;
+				BTLBF_SETTLE(wr[u], wi[u])
+				BTLBF_FETCH(nq[u], non[u], u);
 			}
 #pragma unroll
 			for (int u = 0; u < kEntU; ++u) {
@@ -216,11 +230,12 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 					apply_entry<QUERY>(lds, q[u].z, sd, seg_base);
 					apply_entry<QUERY>(lds, q[u].w, sd, seg_base);
 				}
-				wi[u] += kEntU * kApplyThreads;
-				BTLBF_SETTLE(wr[u], wi[u])
+				q[u] = nq[u];
+				on[u] = non[u];
 			}
 		}
 #undef BTLBF_SETTLE
+#undef BTLBF_FETCH
 	} else {
 		for (uint32_t r = 0; r < n_regions; ++r) {
 			const uint32_t reg = part_in_region(in, ibin, r);
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 				n = cap_entries;
 			const uint4* e4 = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg * cap_entries);
 			const uint32_t n_ev = (n + 3) / 4;
-			for (uint32_t i = tid; i < n_ev; i += kApplyThreads) {
+			for (uint32_t i = tid; i < n_ev; i += NT) {
 				const uint4 q = e4[i];
 				apply_entry<QUERY>(lds, q.x, sd, seg_base);
 				apply_entry<QUERY>(lds, q.y, sd, seg_base);
@@ -241,10 +256,10 @@ __global__ __launch_bounds__(kApplyThreads) void part_apply_kernel(uint8_t* filt
 	if (QUERY)
 		return; // read-only sweep
 	__syncthreads();
-	for (uint32_t base = 0; base < n_vec; base += kApplyThreads * kSegU) {
+	for (uint32_t base = 0; base < n_vec; base += NT * kSegU) {
 #pragma unroll
 		for (int u = 0; u < kSegU; ++u) {
-			const uint32_t i = base + (uint32_t)u * kApplyThreads + tid;
+			const uint32_t i = base + (uint32_t)u * NT + tid;
 			if (i < n_vec)
 				g4[i] = lds4[i];
 		}
@@ -335,17 +350,25 @@ hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_sh
 	if (n_seg == 0)
 		return hipSuccess;
 	const size_t dyn = (size_t)1 << (seg_shift - 3);
-	const void* fn = query ? reinterpret_cast<const void*>(&part_apply_kernel<true>)
-	                       : reinterpret_cast<const void*>(&part_apply_kernel<false>);
-	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-	if (e != hipSuccess)
-		return e;
-	if (query)
-		hipLaunchKernelGGL(part_apply_kernel<true>, dim3((unsigned)n_seg), dim3(kApplyThreads), dyn, s,
-		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, (uint32_t)seg_first, in, sd);
+#define BTLBF_ALAUNCH(Q, NT)                                                                                   \
+	do {                                                                                                       \
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_apply_kernel<Q, NT>),           \
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);              \
+		if (e != hipSuccess)                                                                                   \
+			return e;                                                                                          \
+		hipLaunchKernelGGL((part_apply_kernel<Q, NT>), dim3((unsigned)n_seg), dim3(NT), dyn, s,                \
+		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, (uint32_t)seg_first, in, sd); \
+	} while (0)
+	const bool big = seg_shift > 19; // 128 KiB segments: one workgroup per CU
+	if (query && big)
+		BTLBF_ALAUNCH(true, 1024);
+	else if (query)
+		BTLBF_ALAUNCH(true, 512);
+	else if (big)
+		BTLBF_ALAUNCH(false, 1024);
 	else
-		hipLaunchKernelGGL(part_apply_kernel<false>, dim3((unsigned)n_seg), dim3(kApplyThreads), dyn, s,
-		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, (uint32_t)seg_first, in, sd);
+		BTLBF_ALAUNCH(false, 512);
+#undef BTLBF_ALAUNCH
 	return hipGetLastError();
 }
 
