@@ -1423,10 +1423,10 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 }
 
 // ---- multi-GPU routing (SURVEY.md 8e on the partitioned pipeline) -------------------------------------
-// The GLOBAL filter (size = f->mod.size, a power of two) is cut into 1024 level-0 bins; with W shards
+// The GLOBAL filter (size = f->mod.size, a power of two) is cut into B = 512 (or 1024) level-0 bins; with W shards
 // owner g holds bins [g*1024/W, (g+1)*1024/W).  An origin partitions its probes into those bins (pass
 // A, regions = its CU count); the block of one owner is contiguous, so the exchange is a fixed-size
-// all-to-all of [1024/W bins][regions][cap][kChunk] uint32 plus the entry counts.
+// all-to-all of [B/W bins][regions][cap][kChunk] uint32 plus the entry counts.
 struct RoutePlan {
 	uint32_t bins = 1024; // level-0 bins over the global position space
 	uint32_t shift0 = 0;  // log2(positions per level-0 bin)
@@ -1443,8 +1443,11 @@ int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, uns
 		return fail(BTLBF_EINVAL, "routing needs a bit filter whose global size and shard count are powers of two");
 	if (!part_supported_h(f->hp.h) || !part_hash_fits(f->hp, 1024))
 		return fail(BTLBF_EINVAL, "routing does not support this hash configuration");
-	// BTLBF_ROUTE_BINS (power of two, default 1024) exists for tests: fewer level-0 bins make small
-	// filters exercise the two-split and 32-bit-entry geometries of a 1 TiB filter on 8 GPUs
+	// 512 global level-0 bins (64-entry LDS rings at the origin: few late entries) as long as an entry
+	// -- the position's offset inside its bin -- fits 32 bits, else 1024.  BTLBF_ROUTE_BINS (power of
+	// two) exists for tests: fewer bins make small filters exercise the two-split and 32-bit-entry
+	// geometries of a 1 TiB filter on 8 GPUs
+	rp.bins = ceil_log2(M) - 9 <= 32 && n_shards <= 512 ? 512 : 1024;
 	if (const char* e = getenv("BTLBF_ROUTE_BINS")) {
 		const unsigned b = (unsigned)atoi(e);
 		if (b >= n_shards && b <= 1024 && !(b & (b - 1)))

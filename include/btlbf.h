@@ -234,7 +234,8 @@ int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, 
                       uint64_t* hit_bits, int device, void* stream);
 /* ---- multi-GPU on the partitioned pipeline (large batches) -----------------------
  * Needs a bit filter whose GLOBAL size and shard count are powers of two (2^29..2^42 bits).  The global
- * position space is cut into 1024 level-0 bins; shard g owns bins [g*1024/n, (g+1)*1024/n).  All
+ * position space is cut into B level-0 bins (512, or 1024 above 2^41 bits); shard g owns bins
+ * [g*B/n, (g+1)*B/n).  All
  * pointers are device pointers.
  *  route_plan : byte sizes of ONE origin->owner block for a buffer of `plan_len` bytes.  Every rank
  *               must plan with the same plan_len (e.g. the maximum over ranks) so that blocks have one
