@@ -111,6 +111,24 @@ def test_sharded_routed_partitioned_two_ranks_one_gpu(tmp_path, pipeline):
 
 
 @pytest.mark.gpu
+def test_sharded_routed_four_ranks_one_gpu(tmp_path):
+    """four ranks (four origin blocks per owner, 128 level-0 bins per shard) with the double-buffered
+    schedule of the RCCL path; the concatenated shard bodies must be the reference's filter"""
+    g = load_golden("digests.json")["bf_medium"]
+    bits, h, k, L, world = g["bits"], g["h"], g["k"], g["read_len"], 4
+    n_reads = g["n_reads"] // world
+    mp.spawn(gpu_worker_routed, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L, 0, True),
+             nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+    assert sha(got) == g["body_sha256"]
+    for rank in range(world):
+        res = eval(str(np.load(tmp_path / ("res%d.npy" % rank))[0]))
+        for name, (same, cnt, exp) in res.items():
+            assert same, (rank, name)
+            assert cnt == exp, (rank, name, cnt, exp)
+
+
+@pytest.mark.gpu
 def test_sharded_routed_two_split_levels_and_32bit_entries(tmp_path):
     """the owner-side geometry of a 1 TiB filter on 8 GPUs (32-bit entries, two split passes),
     reproduced at 2^36 bits on 2 ranks by using only 16 level-0 bins (BTLBF_ROUTE_BINS)"""
