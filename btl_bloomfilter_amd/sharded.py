@@ -275,7 +275,13 @@ class ShardedBloomFilter:
         longest = self._max_over_ranks(reads.numel())
         if longest == 0:
             return 0, 0
-        free = torch.cuda.mem_get_info(self.ops.device)[0] if self.ops.device.type == "cuda" else 1 << 40
+        if self.ops.device.type == "cuda":
+            # what the driver reports as free, plus what torch's caching allocator holds without using it
+            # (the block sets of the previous pass): otherwise every pass after the first plans tiny batches
+            free = torch.cuda.mem_get_info(self.ops.device)[0]
+            free += torch.cuda.memory_reserved(self.ops.device) - torch.cuda.memory_allocated(self.ops.device)
+        else:
+            free = 1 << 40
         free = -self._max_over_ranks(-free)  # the smallest over ranks: every rank must plan the same batch
         # per read byte: h*(L-k+1)/L probes * 4 B per entry, ~1.1x capacity; block sets: send (+ receive
         # when there are peers), n_slots of each, + the owner's split levels, which hold 1/8 of a batch
