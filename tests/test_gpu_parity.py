@@ -14,6 +14,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def bf():
+    # torch first, as in every production flow (bench.py, smoke(), the sharded path): its HIP runtime
+    # and context are up before the library makes its first call
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    torch.zeros(1, device="cuda")
     import btl_bloomfilter_amd as m
 
     assert m._lib.load().btlbf_device_count() > 0, "GPU tests need a GPU (and the HIP library)"
