@@ -34,11 +34,11 @@ def slot_of(name):
 
 
 def is_query(name):
-    # QUERY is the 4th template argument of part_hash_kernel<H, POW2, SPACED, QUERY, WINDOW> and the only
-    # one of part_split_kernel / part_apply_kernel
+    # QUERY is the 4th template argument of part_hash_kernel<H, POW2, SPACED, QUERY, WINDOW> and the first
+    # of part_split_kernel<QUERY> / part_apply_kernel<QUERY, NT>
     args = name[name.find("<") + 1:name.find(">(")] if "<" in name else ""
     parts = [a.strip() for a in args.split(",")]
-    q = parts[3] if "part_hash_kernel" in name and len(parts) > 3 else parts[-1]
+    q = parts[3] if "part_hash_kernel" in name and len(parts) > 3 else parts[0]
     return q in ("true", "(bool)1", "1")
 
 
