@@ -319,6 +319,47 @@ class BloomFilter(_Filter):
         return done.value, sec.value
 
 
+class KmerBloomFilter(BloomFilter):
+    """The surface the reference's SWIG module exposes as `BloomFilter` (swig/BloomFilter.i:17-59 =
+    KmerBloomFilter.hpp:17-75): insert / contains take either a k-mer string or a row of precomputed
+    hashes; together with insertSeq() below this replaces both the SWIG/Perl binding and the stale
+    Boost.Python module under pythonInterface/.  K-mer strings are hashed on the GPU like a one-window
+    sequence (always the iterator's hash; see include/btlbf/KmerBloomFilter.hpp for the two corner
+    cases of the reference's tetramer path that are not reproduced)."""
+
+    @staticmethod
+    def _is_kmer(x):
+        return isinstance(x, (str, bytes, bytearray))
+
+    def _kmer(self, x):
+        b = x.encode() if isinstance(x, str) else bytes(x)
+        if len(b) < self.getKmerSize():
+            raise ValueError("k-mer shorter than kmerSize")
+        return np.frombuffer(b[: self.getKmerSize()], np.uint8)
+
+    def insert(self, x, stream=None):
+        if self._is_kmer(x):
+            return self.insertSeqs(self._kmer(x), stream=stream)
+        return super().insert(x, stream=stream)
+
+    def contains(self, x, stream=None):
+        if self._is_kmer(x):
+            hit, _ = self.containsSeqs(self._kmer(x), want_valid=False, stream=stream)[:2]
+            return bool(int(np.asarray(hit).view(np.uint64)[0]) & 1)
+        r = super().contains(x, stream=stream)
+        return bool(r[0]) if np.ndim(x) == 1 else r
+
+
+def insertSeq(bloom, seq, numHashes=None, k=None):
+    """insertSeq(KmerBloomFilter&, const string&, numHashes, k) of BloomFilterUtil.h:9-17 /
+    swig/BloomFilter.i:59: every k-mer of `seq` in one fused launch.  numHashes / k must be the filter's
+    own (the reference hashes with the arguments and inserts with the filter's hash count)."""
+    if numHashes is not None and numHashes != bloom.getHashNum() or k is not None and k != bloom.getKmerSize():
+        raise ValueError("insertSeq: numHashes / k differ from the filter's")
+    s = seq.encode() if isinstance(seq, str) else bytes(seq)
+    bloom.insertSeqs(np.frombuffer(s, np.uint8))
+
+
 class CountingBloomFilter(_Filter):
     """uint8_t counting filter (reference: /root/reference/CountingBloomFilter.hpp, T = uint8_t)"""
 

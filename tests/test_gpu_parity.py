@@ -592,3 +592,36 @@ def test_partitioned_query_equals_direct(bf, bits, miss_reads):
     flt.setQueryMode("auto")
     hit, _, cnt = flt.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
     assert cnt.cpu().tolist() == out["direct"][2] and (hit.cpu().numpy() == out["direct"][0]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# the SWIG module's surface (swig/BloomFilter.i): KmerBloomFilter + insertSeq from Python
+# ---------------------------------------------------------------------------------------------
+def test_swig_surface_kmer_bloom_filter(bf, oracle, tmp_path):
+    rng = np.random.RandomState(5)
+    k, h, bits = 25, 3, 1 << 16
+    seq = rand_seq(rng, 400, 0.02)
+    f = bf.KmerBloomFilter(bits, h, k)
+    bf.insertSeq(f, seq, h, k)
+    mine = np.zeros(bits // 8, np.uint8)
+    oracle.bf_insert_seq(mine, bits, h, k, seq)
+    assert (f.download() == mine).all()
+    pos, hv = oracle.nthash_seq(seq, h, k)
+    # contains(kmer string) == contains(hash row) == the iterator's view, for clean and unclean windows
+    for p in list(pos[:5]) + [int(pos[-1])]:
+        kmer = seq[int(p):int(p) + k]
+        assert f.contains(kmer) and f.contains(kmer.decode())
+    assert f.contains(hv[0].tolist()) is True
+    other = bf.KmerBloomFilter(bits, h, k)
+    assert not other.contains(seq[int(pos[0]):int(pos[0]) + k])
+    other.insert(seq[int(pos[0]):int(pos[0]) + k])       # insert(const char* kmer)
+    other.insert(hv[1].tolist())                          # insert(vector<uint64_t>)
+    assert other.contains(hv[0].tolist()) and other.contains(seq[int(pos[1]):int(pos[1]) + k])
+    assert other.getPop() <= 2 * h and other.getHashNum() == h and other.getKmerSize() == k
+    assert other.getFilterSize() == bits
+    path = str(tmp_path / "swig.bf")
+    f.storeFilter(path)
+    g = bf.KmerBloomFilter(path=path)
+    assert g.getPop() == f.getPop() and (g.download() == mine).all()
+    with pytest.raises(ValueError):
+        bf.insertSeq(f, seq, h + 1, k)
