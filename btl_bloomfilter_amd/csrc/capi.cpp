@@ -941,7 +941,7 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 	a.counts = static_cast<uint64_t*>(ob_cnt.d);
 	a.min_out = static_cast<uint8_t*>(ob_min.d);
 	bool done = false;
-	if (op == OP_BF_CONTAINS) {
+	if (op == OP_BF_CONTAINS || (op == OP_CBF_QUERY && !min_out)) { // minimum counts need the values: direct
 		bool yes = false;
 		if ((rc = want_partitioned_query(f, a, s, &yes)))
 			return rc;
@@ -1024,19 +1024,21 @@ unsigned ceil_log2(uint64_t x)
 	return b;
 }
 
-bool plan_segments(uint64_t mloc, PartPlan& pl)
+// mloc = positions held locally; unit_shift = log2(positions per byte): 3 for bits, 0 for uint8_t counters
+bool plan_segments(uint64_t mloc, PartPlan& pl, uint32_t unit_shift = 3)
 {
 	// 64 KiB segments (two pass-C workgroups per CU) as long as they number at most 2^19, else 128 KiB:
 	// with more than 512 x 1024 segments pass A would need 1024 level-0 bins, whose 32-entry rings make
 	// a quarter of the entries take the late path (measured: pass A 63 -> 54 ms at 512 bins; the
 	// read-only pass C loses 0.7 ms per launch with one workgroup per CU)
-	pl.seg_shift = 19;
-	if (((mloc + (1ull << 19) - 1) >> 19) > 512ull * 1024)
-		pl.seg_shift = 20;
-	if (const char* e = getenv("BTLBF_SEG_SHIFT")) { // tuning knob: 19 or 20
+	const uint32_t small = 16 + unit_shift;
+	pl.seg_shift = small;
+	if (((mloc + (1ull << small) - 1) >> small) > 512ull * 1024)
+		pl.seg_shift = small + 1;
+	if (const char* e = getenv("BTLBF_SEG_SHIFT")) { // tuning knob: 19 or 20 (= 64 / 128 KiB segments)
 		const int v = atoi(e);
 		if (v == 19 || v == 20)
-			pl.seg_shift = (uint32_t)v;
+			pl.seg_shift = (uint32_t)v - 3 + unit_shift;
 	}
 	pl.n_seg = (mloc + (1ull << pl.seg_shift) - 1) >> pl.seg_shift;
 	return pl.n_seg <= 1024ull * 1024;
@@ -1160,6 +1162,7 @@ double probes_per_tile(const btlbf_filter* f, const LayoutParams& lay)
 // run the split levels lv[1..] over the level-0 data `in0`, then the apply / test pass
 int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, int query, hipStream_t s)
 {
+	const int exact = sd.counting && !query; // counter increments: every entry exactly once
 	const int prof_split = query ? BTLBF_PROF_QUERY_SPLIT : BTLBF_PROF_INSERT_SPLIT;
 	const int prof_apply = query ? BTLBF_PROF_QUERY_TEST : BTLBF_PROF_INSERT_APPLY;
 	if (pl.n_levels >= 2 && pl.group_bins) {
@@ -1171,7 +1174,7 @@ int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, in
 			for (int j = 1; j < pl.n_levels; ++j) {
 				ProfSpan ps(f, prof_split, s);
 				HIP_TRY(launch_part_split(f->d_data, in, first_in, abs_first, n_in, pl.lv[j].out(), pl.lv[j].shift,
-				                          in_shift, sd, query, s));
+				                          in_shift, sd, query, exact, s));
 				in = pl.lv[j].in();
 				first_in = 0;
 				abs_first *= pl.lv[j].P;
@@ -1191,7 +1194,8 @@ int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, in
 	uint32_t bins_in = pl.lv[0].bins, in_shift = pl.lv[0].shift;
 	for (int j = 1; j < pl.n_levels; ++j) {
 		ProfSpan ps(f, prof_split, s);
-		HIP_TRY(launch_part_split(f->d_data, in, 0, 0, bins_in, pl.lv[j].out(), pl.lv[j].shift, in_shift, sd, query, s));
+		HIP_TRY(launch_part_split(f->d_data, in, 0, 0, bins_in, pl.lv[j].out(), pl.lv[j].shift, in_shift, sd, query,
+		                          exact, s));
 		in = pl.lv[j].in();
 		bins_in = pl.lv[j].bins;
 		in_shift = pl.lv[j].shift;
@@ -1202,9 +1206,13 @@ int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, in
 }
 
 // decide between the direct (atomicOr per probe) and the partitioned insert
-bool want_partitioned(const btlbf_filter* f, uint64_t len)
+// bit filters: insert; counting filters: incrementAll only (the conservative update of `insert` needs
+// the minimum over a k-mer's h counters, which live in different segments)
+bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 {
-	if (f->kind != BTLBF_BLOOM || f->insert_mode == BTLBF_INSERT_DIRECT)
+	if (f->insert_mode == BTLBF_INSERT_DIRECT)
+		return false;
+	if (f->kind == BTLBF_COUNTING8 ? counting_op != BTLBF_INCREMENT_ALL || f->shard_count != 1 : f->kind != BTLBF_BLOOM)
 		return false;
 	if (!part_supported_h(f->hp.h) || len == 0)
 		return false;
@@ -1225,7 +1233,7 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, Par
 	*ok = false;
 	const uint64_t tile_w = (uint64_t)part_tile_windows();
 	*total_tiles = (base.len + tile_w - 1) / tile_w;
-	if (!plan_segments(f->mod.shard_len, pl))
+	if (!plan_segments(f->mod.shard_len, pl, f->kind == BTLBF_COUNTING8 ? 0 : 3))
 		return BTLBF_OK;
 	PartLevel& l0 = pl.lv[0];
 	if (pl.n_seg <= 1024) {
@@ -1280,6 +1288,7 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 		return rc;
 	PartSide sd;
 	memset(&sd, 0, sizeof sd);
+	sd.counting = f->kind == BTLBF_COUNTING8;
 	for (uint64_t t0 = 0; t0 < total_tiles; t0 += pl.tiles_per_batch) {
 		SeqArgs a = base;
 		a.first_tile = t0;
@@ -1336,6 +1345,9 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	sd.fail_count = reinterpret_cast<unsigned long long*>(extra);
 	sd.fail_list = reinterpret_cast<uint64_t*>(extra + 256);
 	sd.fail_cap = kFailCap;
+	sd.counting = f->kind == BTLBF_COUNTING8;
+	sd.threshold = f->thr;
+	const int direct_op = sd.counting ? OP_CBF_QUERY : OP_BF_CONTAINS;
 	uint64_t* table = sd.fail_list + kFailCap;
 	if (counts)
 		HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
@@ -1371,7 +1383,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 			d.hit_bits = hit_bits;
 			d.valid_bits = nullptr;
 			d.counts = nullptr;
-			HIP_TRY(launch_seq_op(OP_BF_CONTAINS, d, s));
+			HIP_TRY(launch_seq_op(direct_op, d, s));
 		} else if ((rc = resolve_range(f, base, hit_bits, sd.fail_list, n_fail, table, first, n, s))) {
 			return rc;
 		}
@@ -1387,7 +1399,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* yes)
 {
 	*yes = false;
-	if (f->kind != BTLBF_BLOOM || f->shard_count != 1 || f->query_mode == BTLBF_INSERT_DIRECT)
+	if (f->shard_count != 1 || f->query_mode == BTLBF_INSERT_DIRECT)
 		return BTLBF_OK;
 	if (!part_supported_h(f->hp.h) || base.len == 0)
 		return BTLBF_OK;
@@ -1408,7 +1420,8 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 		a.hit_bits = nullptr;
 		a.valid_bits = nullptr;
 		a.counts = reinterpret_cast<uint64_t*>(f->d_scalar);
-		HIP_TRY(launch_seq_op(OP_BF_CONTAINS, a, s));
+		a.min_out = nullptr;
+		HIP_TRY(launch_seq_op(f->kind == BTLBF_COUNTING8 ? OP_CBF_QUERY : OP_BF_CONTAINS, a, s));
 	}
 	unsigned long long c[2] = {0, 0};
 	HIP_TRY(hipMemcpyAsync(c, f->d_scalar, 16, hipMemcpyDeviceToHost, s));
@@ -1665,6 +1678,18 @@ extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
 		if (op != BTLBF_INCREMENT_MIN && op != BTLBF_INCREMENT_ALL)
 			return fail(BTLBF_EINVAL, "op must be BTLBF_INCREMENT_MIN or BTLBF_INCREMENT_ALL");
 		kop = op == BTLBF_INCREMENT_MIN ? OP_CBF_INC_MIN : OP_CBF_INC_ALL;
+		if (order != BTLBF_ORDER_SERIAL && want_partitioned(f, len, op)) {
+			// incrementAll is order-free up to saturation, which is order-free too: exact in any order
+			bool done = false;
+			rc = partitioned_insert(f, a, s, &done);
+			if (rc)
+				return rc;
+			if (done) {
+				if (mem == BTLBF_HOST)
+					HIP_TRY(hipStreamSynchronize(s));
+				return BTLBF_OK;
+			}
+		}
 		if (order == BTLBF_ORDER_SERIAL) {
 			// hash on all CUs, then apply the rows in buffer order on a single lane
 			DevBuf hashes, valid;

@@ -157,6 +157,8 @@ struct PartSide {
 	uint64_t* spill_list;           // routing (multi-GPU): entries that could not be staged, as global positions
 	unsigned long long* spill_count; // nullptr = overflow goes straight to this GPU's array
 	uint64_t spill_cap;
+	uint32_t counting;              // the array holds uint8_t counters (incrementAll / min >= threshold), not bits
+	uint32_t threshold;             // counting query: a probe fails when its counter is below this
 };
 
 // launchers (defined in the .hip files)
@@ -166,9 +168,12 @@ uint32_t part_hash_lds_bytes(const HashParams& hp, uint32_t p0);
 bool part_hash_fits(const HashParams& hp, uint32_t p0);
 hipError_t launch_part_hash(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd, int query,
                             hipStream_t s);
+// exact != 0: every entry counts (counter increments), so readers honour the exact entry count of a
+// region instead of taking its padded last vector whole
 hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_in, uint32_t abs_first, uint32_t n_in_bins,
                              const PartOut& out, uint32_t sub_shift, uint32_t in_shift, const PartSide& sd, int query,
-                             hipStream_t s);
+                             int exact, hipStream_t s);
+// seg_shift = log2(positions per segment); the array holds bits, or uint8_t counters when sd.counting
 hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_shift, uint64_t seg_first, uint64_t n_seg,
                              const PartIn& in, const PartSide& sd, int query, hipStream_t s);
 hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t* table, uint64_t mask, hipStream_t s);

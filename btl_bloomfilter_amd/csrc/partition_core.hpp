@@ -267,12 +267,18 @@ __device__ __forceinline__ void part_report_fail(const PartSide& sd, uint64_t po
 template <bool QUERY>
 __device__ __forceinline__ void part_direct(uint32_t* words, const PartSide& sd, uint64_t lp)
 {
-	if (sd.spill_count)
+	if (sd.spill_count) {
 		part_spill(sd, sd.pos_base + lp);
-	else if (!QUERY)
+	} else if (sd.counting) {
+		if (!QUERY)
+			cbf_inc_sat(words, lp);
+		else if (cbf_read_fresh(words, lp) < sd.threshold)
+			part_report_fail(sd, sd.pos_base + lp);
+	} else if (!QUERY) {
 		bf_set(words, lp);
-	else if (!((bf_word(words, lp) >> (lp & 31)) & 1u))
+	} else if (!((bf_word(words, lp) >> (lp & 31)) & 1u)) {
 		part_report_fail(sd, sd.pos_base + lp);
+	}
 }
 
 

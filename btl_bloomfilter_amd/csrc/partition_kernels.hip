@@ -40,7 +40,8 @@ __device__ __forceinline__ uint32_t part_in_region(const PartIn& in, uint32_t b,
 // the output arrays hold one group at a time (bins numbered relative to the group), which keeps the
 // scratch of the split levels small.  Input bin i is bin i + abs_off of its level in absolute terms
 // (the input arrays themselves are group-relative from the second split level on).
-template <bool QUERY>
+// EXACT: every entry counts (counter increments): the padded tail of a region is not taken whole.
+template <bool QUERY, bool EXACT>
 __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, const PartIn in, const PartOut out,
                                                                  const uint32_t slices, const uint32_t sub_shift,
                                                                  const uint32_t in_shift, const uint32_t first_in,
@@ -82,17 +83,22 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 #pragma unroll
 			for (int v = 0; v < kVec; ++v) {
 				const uint32_t e4[4] = {nxt[v].x, nxt[v].y, nxt[v].z, nxt[v].w};
-				// whole vectors: a region's tail is padded with copies of its last entry (part_finish)
-				live |= (uint32_t)(base + (uint32_t)v * kPartThreads + tid < n_vec) << v;
+				// whole vectors: a region's tail is padded with copies of its last entry (part_finish),
+				// which is harmless for OR / test; counting takes exactly n entries
+				const uint32_t vi = base + (uint32_t)v * kPartThreads + tid;
+				if (!EXACT)
+					live |= (uint32_t)(vi < n_vec) << v;
 #pragma unroll
 				for (int c = 0; c < 4; ++c) {
 					bin[v * 4 + c] = e4[c] >> sub_shift;
 					val[v * 4 + c] = e4[c] & sub_mask;
+					if (EXACT)
+						live |= (uint32_t)(vi * 4 + c < n) << (v * 4 + c);
 				}
 				const uint32_t i = base + kPartThreads * kVec + (uint32_t)v * kPartThreads + tid;
 				nxt[v] = i < n_vec ? src[i] : make_uint4(0, 0, 0, 0);
 			}
-			part_round<kPartThreads, kVec * 4, 4>(pl, out, bin0, g, bin, val, live, ovf STAMP_PASS);
+			part_round<kPartThreads, kVec * 4, EXACT ? 1 : 4>(pl, out, bin0, g, bin, val, live, ovf STAMP_PASS);
 		}
 	}
 	part_finish<kPartThreads>(pl, out, bin0, g, ovf);
@@ -104,28 +110,56 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 // Input bin blockIdx.x holds the entries of segment seg_first + blockIdx.x (group-relative numbering).
 static constexpr uint32_t kApplyMaxRegions = 1024; // region table kept in LDS (more: plain loop)
 
-template <bool QUERY>
+// what pass C does with an entry (= position inside the segment held in LDS)
+enum ApplyMode : int {
+	APPLY_BIT_OR = 0,   // BloomFilter::insert
+	APPLY_BIT_TEST = 1, // BloomFilter::contains: clear bit -> fail list
+	APPLY_CNT_INC = 2,  // CountingBloomFilter::incrementAll: saturating +1 (CountingBloomFilter.hpp:171-181)
+	APPLY_CNT_TEST = 3  // CountingBloomFilter::contains: counter < threshold -> fail list
+};
+
+template <int MODE>
 __device__ __forceinline__ void apply_entry(uint32_t* lds, uint32_t e, const PartSide& sd, uint64_t seg_base)
 {
-	if (!QUERY)
+	if (MODE == APPLY_BIT_OR) {
 		atomicOr(&lds[e >> 5], 1u << (e & 31));
-	else if (!((lds[e >> 5] >> (e & 31)) & 1u))
-		part_report_fail(sd, sd.pos_base + (seg_base | e));
+	} else if (MODE == APPLY_BIT_TEST) {
+		if (!((lds[e >> 5] >> (e & 31)) & 1u))
+			part_report_fail(sd, sd.pos_base + (seg_base | e));
+	} else if (MODE == APPLY_CNT_INC) {
+		// uint8_t counters, four to an LDS word: CAS the word, leave 255 alone
+		uint32_t* w = &lds[e >> 2];
+		const uint32_t sh = (e & 3) * 8;
+		uint32_t old = *w;
+		for (;;) {
+			if (((old >> sh) & 0xffu) == 0xffu)
+				break;
+			const uint32_t prev = atomicCAS(w, old, old + (1u << sh));
+			if (prev == old)
+				break;
+			old = prev;
+		}
+	} else {
+		if (((lds[e >> 2] >> ((e & 3) * 8)) & 0xffu) < sd.threshold)
+			part_report_fail(sd, sd.pos_base + (seg_base | e));
+	}
 }
 
-// Memory-level parallelism is what this kernel lives on (two workgroups per CU): the segment is
-// fetched with 8 independent 16-byte loads per thread, and the entries of ALL regions are walked as
-// one virtual array with 4 independent loads per thread in flight.
-// NT = 512 for 64 KiB segments (two workgroups per CU), 1024 for 128 KiB segments (one per CU: twice
-// the loads in flight per workgroup make up for the missing second one)
-template <bool QUERY, int NT>
+// Memory-level parallelism is what this kernel lives on: the segment is fetched with 8 independent
+// 16-byte loads per thread, and the entries of ALL regions are walked as one virtual array with 4
+// independent loads per thread in flight (the first batch is requested before the segment is waited for).
+// NT = 512 for 64 KiB segments (two workgroups per CU), 1024 for 128 KiB segments (one per CU).
+// Every region is read up to its exact entry count (its last vector may be padded).
+template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_t local_bytes,
-                                                                 uint32_t seg_shift, uint32_t seg_first,
-                                                                 const PartIn in, const PartSide sd)
+                                                        uint32_t seg_shift, uint32_t seg_first,
+                                                        const PartIn in, const PartSide sd)
 {
+	constexpr bool QUERY = (MODE & 1) != 0;
+	constexpr uint32_t kUnitShift = MODE >= APPLY_CNT_INC ? 0 : 3; // log2(positions per byte)
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	__shared__ uint32_t any;
-	__shared__ uint32_t r_nev[kApplyMaxRegions]; // 16-byte vectors of entries in region r of this bin
+	__shared__ uint32_t r_n[kApplyMaxRegions];   // entries in region r of this bin
 	__shared__ uint32_t r_reg[kApplyMaxRegions]; // its index into in.cnt / in.ent
 	const uint32_t tid = threadIdx.x;
 	const uint32_t ibin = blockIdx.x;
@@ -144,7 +178,7 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 			n = cap_entries;
 		mine |= n;
 		if (tabled) {
-			r_nev[r] = (n + 3) / 4; // whole vectors: the tail is padded with copies of the last entry
+			r_n[r] = n;
 			r_reg[r] = reg;
 		}
 	}
@@ -153,7 +187,7 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 	__syncthreads();
 	if (!any)
 		return; // untouched segment: no traffic at all
-	const uint64_t seg_bytes = 1ull << (seg_shift - 3);
+	const uint64_t seg_bytes = 1ull << (seg_shift - kUnitShift);
 	const uint64_t byte0 = (uint64_t)seg * seg_bytes;
 	const uint64_t seg_base = (uint64_t)seg << seg_shift;
 	uint64_t nbytes = local_bytes - byte0;
@@ -164,26 +198,25 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 	uint4* g4 = reinterpret_cast<uint4*>(filter + byte0);
 	constexpr int kSegU = 8;
 	constexpr int kEntU = 4;
-	// kEntU walkers per thread over the virtual concatenation of the regions' vectors; the first batch
-	// of entry loads is issued BEFORE the segment is waited for, and from then on the next batch is
-	// always in flight while the current one is applied
-	uint32_t wr[kEntU], wi[kEntU];
+	// kEntU walkers per thread over the virtual concatenation of the regions' vectors
+	uint32_t wr[kEntU], wi[kEntU], left[kEntU]; // region, vector inside it, entries from that vector on (0: done)
 	uint4 q[kEntU];
-	bool on[kEntU];
 #define BTLBF_SETTLE(r, i)                               \
 	while ((r) < n_regions) {                            \
-		const uint32_t nev__ = r_nev[(r)];               \
+		const uint32_t nev__ = (r_n[(r)] + 3) / 4;       \
 		if ((i) < nev__)                                 \
 			break;                                       \
 		(i) -= nev__;                                    \
 		++(r);                                           \
 	}
-#define BTLBF_FETCH(dst, flag, u)                                                                              \
+#define BTLBF_FETCH(dst, lft, u)                                                                               \
 	do {                                                                                                       \
-		flag = wr[u] < n_regions;                                                                              \
+		lft = 0;                                                                                               \
 		dst = make_uint4(0, 0, 0, 0);                                                                          \
-		if (flag)                                                                                              \
+		if (wr[u] < n_regions) {                                                                               \
+			lft = r_n[wr[u]] - wi[u] * 4;                                                                      \
 			dst = reinterpret_cast<const uint4*>(in.ent + (uint64_t)r_reg[wr[u]] * cap_entries)[wi[u]];        \
+		}                                                                                                      \
 	} while (0)
 	if (tabled) {
 #pragma unroll
@@ -191,7 +224,7 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 			wr[u] = 0;
 			wi[u] = (uint32_t)u * NT + tid;
 			BTLBF_SETTLE(wr[u], wi[u])
-			BTLBF_FETCH(q[u], on[u], u);
+			BTLBF_FETCH(q[u], left[u], u);
 		}
 	}
 	for (uint32_t base = 0; base < n_vec; base += NT * kSegU) {
@@ -213,25 +246,27 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 	__syncthreads();
 	uint32_t* lds = reinterpret_cast<uint32_t*>(dyn);
 	if (tabled) {
-		while (on[0]) {
+		while (left[0]) {
 			uint4 nq[kEntU];
-			bool non[kEntU];
+			uint32_t nleft[kEntU];
 #pragma unroll
 			for (int u = 0; u < kEntU; ++u) {
 				wi[u] += kEntU * NT;
 				BTLBF_SETTLE(wr[u], wi[u])
-				BTLBF_FETCH(nq[u], non[u], u);
+				BTLBF_FETCH(nq[u], nleft[u], u);
 			}
 #pragma unroll
 			for (int u = 0; u < kEntU; ++u) {
-				if (on[u]) {
-					apply_entry<QUERY>(lds, q[u].x, sd, seg_base);
-					apply_entry<QUERY>(lds, q[u].y, sd, seg_base);
-					apply_entry<QUERY>(lds, q[u].z, sd, seg_base);
-					apply_entry<QUERY>(lds, q[u].w, sd, seg_base);
-				}
+				if (left[u] > 0)
+					apply_entry<MODE>(lds, q[u].x, sd, seg_base);
+				if (left[u] > 1)
+					apply_entry<MODE>(lds, q[u].y, sd, seg_base);
+				if (left[u] > 2)
+					apply_entry<MODE>(lds, q[u].z, sd, seg_base);
+				if (left[u] > 3)
+					apply_entry<MODE>(lds, q[u].w, sd, seg_base);
 				q[u] = nq[u];
-				on[u] = non[u];
+				left[u] = nleft[u];
 			}
 		}
 #undef BTLBF_SETTLE
@@ -242,15 +277,9 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 			uint32_t n = in.cnt[reg];
 			if (n > cap_entries)
 				n = cap_entries;
-			const uint4* e4 = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg * cap_entries);
-			const uint32_t n_ev = (n + 3) / 4;
-			for (uint32_t i = tid; i < n_ev; i += NT) {
-				const uint4 q = e4[i];
-				apply_entry<QUERY>(lds, q.x, sd, seg_base);
-				apply_entry<QUERY>(lds, q.y, sd, seg_base);
-				apply_entry<QUERY>(lds, q.z, sd, seg_base);
-				apply_entry<QUERY>(lds, q.w, sd, seg_base);
-			}
+			const uint32_t* e1 = in.ent + (uint64_t)reg * cap_entries;
+			for (uint32_t i = tid; i < n; i += NT)
+				apply_entry<MODE>(lds, e1[i], sd, seg_base);
 		}
 	}
 	if (QUERY)
@@ -323,24 +352,31 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bi
 
 hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_in, uint32_t abs_first, uint32_t n_in_bins,
                              const PartOut& out, uint32_t sub_shift, uint32_t in_shift, const PartSide& sd, int query,
-                             hipStream_t s)
+                             int exact, hipStream_t s)
 {
 	if (n_in_bins == 0)
 		return hipSuccess;
 	const size_t dyn = part_lds_bytes(out.P);
-	const void* fn = query ? reinterpret_cast<const void*>(&part_split_kernel<true>)
-	                       : reinterpret_cast<const void*>(&part_split_kernel<false>);
-	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-	if (e != hipSuccess)
-		return e;
 	const uint32_t slices = out.regions;
 	const dim3 grid(n_in_bins * slices);
-	if (query)
-		hipLaunchKernelGGL(part_split_kernel<true>, grid, dim3(kPartThreads), dyn, s, filter, in, out, slices,
-		                   sub_shift, in_shift, first_in, abs_first - first_in, sd);
+#define BTLBF_SLAUNCH(Q, E)                                                                                    \
+	do {                                                                                                       \
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_split_kernel<Q, E>),            \
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);              \
+		if (e != hipSuccess)                                                                                   \
+			return e;                                                                                          \
+		hipLaunchKernelGGL((part_split_kernel<Q, E>), grid, dim3(kPartThreads), dyn, s, filter, in, out, slices, \
+		                   sub_shift, in_shift, first_in, abs_first - first_in, sd);                            \
+	} while (0)
+	if (query && exact)
+		BTLBF_SLAUNCH(true, true);
+	else if (query)
+		BTLBF_SLAUNCH(true, false);
+	else if (exact)
+		BTLBF_SLAUNCH(false, true);
 	else
-		hipLaunchKernelGGL(part_split_kernel<false>, grid, dim3(kPartThreads), dyn, s, filter, in, out, slices,
-		                   sub_shift, in_shift, first_in, abs_first - first_in, sd);
+		BTLBF_SLAUNCH(false, false);
+#undef BTLBF_SLAUNCH
 	return hipGetLastError();
 }
 
@@ -349,25 +385,39 @@ hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_sh
 {
 	if (n_seg == 0)
 		return hipSuccess;
-	const size_t dyn = (size_t)1 << (seg_shift - 3);
-#define BTLBF_ALAUNCH(Q, NT)                                                                                   \
+	const int mode = (sd.counting ? APPLY_CNT_INC : APPLY_BIT_OR) + (query ? 1 : 0);
+	const size_t dyn = (size_t)1 << (seg_shift - (sd.counting ? 0 : 3)); // bytes of one segment
+#define BTLBF_ALAUNCH(M, NT)                                                                                   \
 	do {                                                                                                       \
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_apply_kernel<Q, NT>),           \
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_apply_kernel<M, NT>),           \
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);              \
 		if (e != hipSuccess)                                                                                   \
 			return e;                                                                                          \
-		hipLaunchKernelGGL((part_apply_kernel<Q, NT>), dim3((unsigned)n_seg), dim3(NT), dyn, s,                \
+		hipLaunchKernelGGL((part_apply_kernel<M, NT>), dim3((unsigned)n_seg), dim3(NT), dyn, s,                \
 		                   static_cast<uint8_t*>(filter), local_bytes, seg_shift, (uint32_t)seg_first, in, sd); \
 	} while (0)
-	const bool big = seg_shift > 19; // 128 KiB segments: one workgroup per CU
-	if (query && big)
-		BTLBF_ALAUNCH(true, 1024);
-	else if (query)
-		BTLBF_ALAUNCH(true, 512);
-	else if (big)
-		BTLBF_ALAUNCH(false, 1024);
+#define BTLBF_ALAUNCH_M(NT)                      \
+	do {                                         \
+		switch (mode) {                          \
+		case APPLY_BIT_OR:                       \
+			BTLBF_ALAUNCH(APPLY_BIT_OR, NT);     \
+			break;                               \
+		case APPLY_BIT_TEST:                     \
+			BTLBF_ALAUNCH(APPLY_BIT_TEST, NT);   \
+			break;                               \
+		case APPLY_CNT_INC:                      \
+			BTLBF_ALAUNCH(APPLY_CNT_INC, NT);    \
+			break;                               \
+		default:                                 \
+			BTLBF_ALAUNCH(APPLY_CNT_TEST, NT);   \
+			break;                               \
+		}                                        \
+	} while (0)
+	if (dyn > 64 * 1024) // 128 KiB segments: one workgroup per CU
+		BTLBF_ALAUNCH_M(1024);
 	else
-		BTLBF_ALAUNCH(false, 512);
+		BTLBF_ALAUNCH_M(512);
+#undef BTLBF_ALAUNCH_M
 #undef BTLBF_ALAUNCH
 	return hipGetLastError();
 }

@@ -625,3 +625,37 @@ def test_swig_surface_kmer_bloom_filter(bf, oracle, tmp_path):
     assert g.getPop() == f.getPop() and (g.download() == mine).all()
     with pytest.raises(ValueError):
         bf.insertSeq(f, seq, h + 1, k)
+
+
+# ---------------------------------------------------------------------------------------------
+# counting filter through the partitioned pipeline: incrementAll (exact, saturating) and contains()
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nbytes,k,h", [(1 << 27, 25, 3), (5 << 24, 31, 4), (1 << 30, 25, 3)])
+def test_partitioned_counting_increment_all_and_query(bf, nbytes, k, h):
+    import torch
+
+    L, thr = 150, 2
+    reads = bf.synth_reads_device(21, 0, 60000, L)
+    sat = reads[: 3 * L].repeat(300)  # 300 copies of three reads: their counters saturate at 255
+    buf = torch.cat([reads, reads[: 20000 * L], sat])
+    a, b = bf.CountingBloomFilter(nbytes, h, k, thr), bf.CountingBloomFilter(nbytes, h, k, thr)
+    for f, mode in ((a, "direct"), (b, "partitioned")):
+        f.setInsertMode(mode)
+        f.setQueryMode(mode)
+        f.insertSeqs(buf, read_len=L, increment_all=True)
+    torch.cuda.synchronize()
+    ca, cb = a.download(), b.download()
+    assert ca.max() == 255 and (ca == cb).all()
+    assert a.popCount() == b.popCount() and a.filtered_popcount() == b.filtered_popcount()
+    # reads inserted twice pass the threshold, reads inserted once mostly do not, foreign reads do not
+    q = torch.cat([reads[: 25000 * L], bf.synth_reads_device(22, 0, 50, L)])
+    ha, va, na = a.containsSeqs(q, read_len=L, want_counts=True)
+    hb, vb, nb = b.containsSeqs(q, read_len=L, want_counts=True)
+    torch.cuda.synchronize()
+    assert na.tolist() == nb.tolist() and bool((ha == hb).all().item()) and bool((va == vb).all().item())
+    assert 20000 * (L - k + 1) <= int(na[1]) < int(na[0])
+    # the conservative update (`insert`) is not partitioned: it must still take the direct kernel
+    c = bf.CountingBloomFilter(nbytes, h, k, thr)
+    c.setInsertMode("partitioned")
+    c.insertSeqs(reads, read_len=L)
+    assert 0 < c.popCount() <= a.popCount()
