@@ -7,7 +7,8 @@
 namespace btlbf {
 
 // 1024-thread workgroups (4 waves per SIMD; one workgroup per CU because the staging rings fill the
-// LDS) with 4 windows per lane in pass A and 16 entries per lane in pass B: <= 128 VGPRs
+// LDS) with 8 windows per lane and tile in pass A (two rounds of 4) and 16 entries per lane and round
+// in pass B: <= 128 VGPRs
 static constexpr int kPartThreads = 1024;
 static constexpr int kPartW = 8;                        // windows per lane and tile in pass A ...
 static constexpr int kPartHalf = 4;                     // ... partitioned in two rounds of 4 (the rings hold one)

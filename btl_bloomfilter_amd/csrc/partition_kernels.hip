@@ -18,10 +18,11 @@
 // full, so every global write is one aligned 128-byte line.  Every workgroup writes into its OWN
 // region of every bin (region = (bin, writer)), so chunk slots are handed out from an LDS counter:
 // no global atomics in passes A and B.  The number of ENTRIES of each region is published at kernel
-// end (the tail chunk is partial).  Entries that do not fit (a region over capacity, or a bin that
-// receives more than about two rings' worth inside one round) take the overflow path: applied to
-// the filter directly (single GPU) or appended to a spill list of global positions (multi-GPU
-// routing) -- never dropped.
+// end; the tail chunk is partial and padded to a whole 16-byte vector with copies of its last entry
+// (harmless for OR / test; the counting passes read exactly the published count).  Entries that do
+// not fit (a region over capacity, or a bin that receives more than its ring and the space freed by
+// one flush hold inside one round) take the overflow path: applied to the filter directly (single
+// GPU) or appended to a spill list of global positions (multi-GPU routing) -- never dropped.
 #include "partition_core.hpp"
 
 namespace btlbf {
