@@ -347,6 +347,18 @@ def main():
                                          "note": "seed-43 reads against the filter of the timed run; AUTO samples the "
                                                  "batch, sees misses and keeps the direct early-exit gather kernel"}
                 del reads_miss
+            # the measured random-access ceilings of this GPU on the same array (bare kernels:
+            # independent 4-byte loads / 4-byte atomicOr at uniformly random 64-byte-aligned offsets)
+            try:
+                ng, tg = flt.microbench(0, 1 << 31)
+                na, ta = flt.microbench(1, 1 << 30)
+                out["random_access_ceiling"] = {
+                    "gather_Gprobes_s": ng / tg / 1e9, "gather_GB_s_of_64B_sectors": ng / tg * 64 / 1e9,
+                    "atomic_or_Gprobes_s": na / ta / 1e9,
+                    "note": "what one probe per random 64-B sector can reach here; the direct kernels sit on these "
+                            "ceilings, the partitioned pipeline exists to get off them (DESIGN.md section 5)"}
+            except Exception as exc:
+                out["random_access_ceiling"] = {"error": repr(exc)}
             if not args.no_cpu_baseline:
                 del reads, hit_bits
                 try:
