@@ -48,12 +48,25 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 
 	__syncthreads(); // tables and partition state ready
 	STAMP_DECL;
+	StageRaw<kPartW> raw;
+	if (t_begin < t_end)
+		seq_stage_load<kPartThreads, kPartW>(raw, a.seq, a.len, k, t_begin * (uint64_t)kPartTile);
 	for (uint64_t t = t_begin; t < t_end; ++t) {
 		const uint64_t g0 = t * (uint64_t)kPartTile;
 		STAMP(0);
-		const uint32_t mis = seq_stage_tile<kPartThreads, kPartW, false>(tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+		// this tile's words were requested a whole tile ago; the next tile's are requested now and stay
+		// in flight while this one is hashed and partitioned
+#ifdef BTLBF_PHASE_STAMPS
+		const uint32_t mis = seq_stage_convert<kPartThreads, kPartW, false, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+		STAMP(1); // conversion of this thread's words
+		__syncthreads();
+		STAMP(3); // waiting for the other waves
+#else
+		const uint32_t mis = seq_stage_convert<kPartThreads, kPartW, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+#endif
+		if (t + 1 < t_end)
+			seq_stage_load<kPartThreads, kPartW>(raw, a.seq, a.len, k, g0 + kPartTile);
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
-		STAMP(1);
 
 		// the lane hashes its 8 consecutive windows with ONE start-up; after every 4 windows the
 		// 4*H entries collected so far go through a partition round (the rolling state stays in

@@ -113,6 +113,34 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t x, uint32_t L, uint32_t i
 	return r;
 }
 
+// The raw words of a tile this thread converts (its first KW/4+1 words; more only for large k).
+template <int KW = kW>
+struct StageRaw {
+	uint32_t w[KW / 4 + 1];
+};
+
+// Request this thread's words of the tile that starts at byte offset g0 (zero past the data).  Kept
+// apart from the conversion so that a kernel can have the NEXT tile's loads in flight while it works
+// on the current one (pass A of the partitioned pipeline).
+template <int NT, int KW = kW>
+__device__ __forceinline__ void seq_stage_load(StageRaw<KW>& raw, const uint8_t* seq, uint64_t len, uint32_t k,
+                                               uint64_t g0)
+{
+	constexpr uint32_t kTileW = NT * KW;
+	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(seq + g0) & 3);
+	uint64_t need = len > g0 ? len - g0 : 0;
+	if (need > (uint64_t)(kTileW + k - 1))
+		need = kTileW + k - 1;
+	const uint32_t n_words = need ? (mis + (uint32_t)need + 3) / 4 : 0;
+#pragma unroll
+	for (int a = 0; a < KW / 4 + 1; ++a) {
+		const uint32_t j = threadIdx.x + (uint32_t)a * NT;
+		raw.w[a] = 0;
+		if (j < n_words)
+			raw.w[a] = *reinterpret_cast<const uint32_t*>(seq + g0 - mis + 4ull * j);
+	}
+}
+
 // Stage the tile that starts at byte offset g0: every thread converts aligned 4-byte words of the
 // read buffer (coalesced loads) through the LUT and writes them to LDS, so all waves share the work.
 // Ends with a __syncthreads(); begins with one so that the previous tile has been fully consumed.
@@ -120,10 +148,12 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t x, uint32_t L, uint32_t i
 // index of window w's first base is w + mis.
 // LEAD_BARRIER = false: the caller guarantees that nobody still reads the previous tile (pass A of
 // the partitioned pipeline: its last partition round ends with a barrier after the last tile read).
-template <int NT, int KW = kW, bool LEAD_BARRIER = true>
-__device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_cap, SeqShared& sh,
-                                                   const uint8_t* seq, uint64_t len, const LayoutParams& lay,
-                                                   uint32_t k, uint64_t g0, uint32_t tile_off)
+// TRAIL_BARRIER = false: the caller provides the barrier between these writes and the first read.
+template <int NT, int KW = kW, bool LEAD_BARRIER = true, bool TRAIL_BARRIER = true>
+__device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, uint8_t* tile, uint32_t tile_cap,
+                                                      SeqShared& sh, const uint8_t* seq, uint64_t len,
+                                                      const LayoutParams& lay, uint32_t k, uint64_t g0,
+                                                      uint32_t tile_off)
 {
 	constexpr uint32_t kTileW = NT * KW;
 	const uint32_t tid = threadIdx.x;
@@ -162,22 +192,14 @@ __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_
 		}
 		reinterpret_cast<uint32_t*>(tile)[j] = o;
 	};
-	// the thread's first words are all requested before any is converted (one memory latency per
-	// tile, not one per word)
+	// the thread's first words were all requested before any is converted (one memory latency per
+	// tile, not one per word -- or none, when the caller asked for them a tile ahead)
 	constexpr int kAhead = KW / 4 + 1;
-	uint32_t raw[kAhead];
-#pragma unroll
-	for (int a = 0; a < kAhead; ++a) {
-		const uint32_t j = tid + (uint32_t)a * NT;
-		raw[a] = 0;
-		if (j < n_words)
-			raw[a] = *reinterpret_cast<const uint32_t*>(seq + g0 - mis + 4ull * j);
-	}
 #pragma unroll
 	for (int a = 0; a < kAhead; ++a) {
 		const uint32_t j = tid + (uint32_t)a * NT;
 		if (j < tile_cap / 4)
-			convert(j, raw[a]);
+			convert(j, pre.w[a]);
 	}
 	for (uint32_t j = tid + kAhead * NT; j < tile_cap / 4; j += NT) { // large k only
 		uint32_t w = 0;
@@ -208,8 +230,21 @@ __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_
 			atomicAnd(reinterpret_cast<uint32_t*>(tile) + (li >> 2), ~(kBaseGood << (8 * (li & 3))));
 		}
 	}
-	__syncthreads();
+	if (TRAIL_BARRIER)
+		__syncthreads();
 	return mis;
+}
+
+// load + convert in one go (the direct kernels)
+template <int NT, int KW = kW, bool LEAD_BARRIER = true, bool TRAIL_BARRIER = true>
+__device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_cap, SeqShared& sh,
+                                                   const uint8_t* seq, uint64_t len, const LayoutParams& lay,
+                                                   uint32_t k, uint64_t g0, uint32_t tile_off)
+{
+	StageRaw<KW> raw;
+	seq_stage_load<NT, KW>(raw, seq, len, k, g0);
+	return seq_stage_convert<NT, KW, LEAD_BARRIER, TRAIL_BARRIER>(raw, tile, tile_cap, sh, seq, len, lay, k, g0,
+	                                                              tile_off);
 }
 
 // hash values of one window.  Plain ntHash: hash i is recomputed from the canonical value where it

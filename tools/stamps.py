@@ -17,5 +17,5 @@ raw.btlbf_debug_stamps(out)
 f.insertSeqs(reads, read_len=150); torch.cuda.synchronize()
 raw.btlbf_debug_stamps(out)
 v = list(out); tot = sum(v)
-names = ["loop+bitmap", "tile staging", "hash (start-up + rolls)", "-", "phase 1: atomics + ring write (+barrier)", "-", "phase 2: flush (+barrier)", "phase 3: late entries", "-", "finish"]
+names = ["loop+bitmap", "tile staging: own loads + conversion", "hash (start-up + rolls)", "tile staging: barrier wait", "phase 1: atomics + ring write (+barrier)", "-", "phase 2: flush (+barrier)", "phase 3: late entries", "-", "finish"]
 for n, x in zip(names, v): print("%-20s %6.2f %%  %d" % (n, 100.0 * x / tot, x))
