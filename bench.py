@@ -179,6 +179,11 @@ def main():
     import btl_bloomfilter_amd as m
     from btl_bloomfilter_amd import _lib
 
+    # rehearsal mode (tests only): all ranks on cuda:0 with the gloo backend, to run the N > 1 code path
+    # of this file on a one-GPU box; RCCL itself needs one GPU per rank
+    rehearsal = bool(os.environ.get("BTLBF_BENCH_REHEARSAL"))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = _lib.load()
@@ -187,7 +192,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n_reads = args.reads
     bits_per_gpu = 1 << args.log2_bits
@@ -270,10 +278,11 @@ def main():
         t_ins.append(e[0].elapsed_time(e[1]) * 1e-3)
         t_qry.append(e[2].elapsed_time(e[3]) * 1e-3)
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        rdev = "cpu" if rehearsal else dev  # gloo reduces host tensors
+        t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = counts.clone()
+        c = counts.to(rdev)
         dist.all_reduce(c)
         tot_counts = c.tolist()
     else:

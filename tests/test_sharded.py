@@ -153,3 +153,25 @@ def test_sharded_routed_two_split_levels_and_32bit_entries(tmp_path):
     body = ref.download()
     got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
     assert (got == body).all()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's N > 1 path (launch contract, sharded filter, max-over-ranks timing, the JSON line) with
+    two ranks on the one GPU and the gloo backend; RCCL itself needs one GPU per rank"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BTLBF_BENCH_REHEARSAL="1", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "1", "--reads", "200000", "--log2-bits", "30", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["kmers_per_pass"] == 2 * 200000 * 120
