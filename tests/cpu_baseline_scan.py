@@ -1,3 +1,5 @@
+"""Thread scaling of the genuine reference build on this host (checker-side diagnostic for bench.py's
+cpu_baseline; lives under tests/ because it runs oracle/_ref)."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 from oracle.pyoracle import Ref
