@@ -192,6 +192,18 @@ class BloomFilter
 		const double m = double(getFilterSize()), h = double(getHashNum());
 		return std::pow(1.0 - std::pow(1.0 - 1.0 / m, double(btlbf_get_n_entry(m_f)) * h), h);
 	}
+	// false-positive rate of calling a redundant entry unique (BloomFilter.hpp:333-341; host arithmetic
+	// over nEntry terms exactly as in the reference)
+	double getRedudancyFPR()
+	{
+		const double m = double(getFilterSize()), h = double(getHashNum());
+		const uint64_t n = btlbf_get_n_entry(m_f);
+		auto fpr = [&](double e) { return std::pow(1.0 - std::pow(1.0 - 1.0 / m, e * h), h); };
+		double total = std::log(fpr(1));
+		for (uint64_t i = 2; i < n; ++i)
+			total = std::log(std::exp(total) + fpr(double(i)));
+		return std::exp(total) / double(n);
+	}
 	unsigned getHashNum() const { return btlbf_hash_num(m_f); }
 	unsigned getKmerSize() const { return btlbf_kmer_size(m_f); }
 	uint64_t getFilterSize() const { return btlbf_size(m_f); }
