@@ -29,3 +29,38 @@ def test_reference_unit_scenarios_through_shims():
     r = subprocess.run([exe, GOLDEN], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all shim tests passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_example_tool_build_and_query(tmp_path, oracle):
+    """examples/bloom_tool: build a filter from a gzipped FASTQ, store it, load it again and query"""
+    import gzip
+
+    import numpy as np
+
+    import __graft_entry__ as g
+
+    g.build_shim_test()
+    exe = os.path.join(ROOT, "examples", "bloom_tool")
+    rng = np.random.RandomState(3)
+    reads = ["".join(rng.choice(list("ACGT"), 100)) for _ in range(300)]
+    fq = tmp_path / "r.fq.gz"
+    with gzip.open(fq, "wt") as fh:
+        for i, s in enumerate(reads):
+            fh.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    out = tmp_path / "r.bf"
+    bits, h, k = 1 << 20, 3, 21
+    r = subprocess.run([exe, "build", str(fq), str(bits), str(h), str(k), str(out)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "records 300" in r.stdout, r.stdout + r.stderr
+    mine = np.zeros(bits // 8, np.uint8)
+    for s in reads:
+        oracle.bf_insert_seq(mine, bits, h, k, s.encode())
+    body = open(out, "rb").read()
+    assert body.endswith(mine.tobytes()) and body.startswith(b"[BTLBloomFilter_v1]")
+    fa = tmp_path / "q.fa"
+    fa.write_text(">a\n%s\n>b\n%s\n" % (reads[0], "".join(rng.choice(list("ACGT"), 500))))
+    r = subprocess.run([exe, "query", str(out), str(fa)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    n_all = (100 - k + 1) + (500 - k + 1)
+    assert ("k-mers %d " % n_all) in r.stdout and ("found %d " % (100 - k + 1)) in r.stdout, r.stdout
