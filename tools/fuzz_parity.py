@@ -30,6 +30,15 @@ def one_case(rng, it):
     if rng.random() < 0.3:  # skew: many copies of a few reads
         reads[rng.integers(0, n_reads, n_reads // 2)] = reads[0]
     counting = rng.random() < 0.25
+    seeds, h2 = None, 1
+    if not counting and k >= 4 and rng.random() < 0.2:  # spaced seeds (stHashIterator): h = n_seeds * h2
+        n_seeds, h2 = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+        h = n_seeds * h2
+        seeds = []
+        for _ in range(n_seeds):
+            bits01 = (rng.random(k) < 0.7).astype(int)
+            bits01[0] = bits01[-1] = 1
+            seeds.append("".join(map(str, bits01)))
     ragged = rng.random() < 0.3
     flat = torch.from_numpy(reads.reshape(-1).copy()).cuda()
     kw = {}
@@ -49,6 +58,8 @@ def one_case(rng, it):
             f = m.CountingBloomFilter(max(bits // 8, 64), h, k, thr)
         else:
             f = m.BloomFilter(bits // 8 * 8, h, k)
+            if seeds:
+                f.setSpacedSeeds(seeds, h2)
         f.setInsertMode(mode, scratch_bytes=scratch if mode == "partitioned" else 0)
         f.setQueryMode(mode)
         if counting:
@@ -65,7 +76,8 @@ def one_case(rng, it):
     a, b = res
     same = [bool((a[0] == b[0]).all()), bool((a[1] == b[1]).all()), a[2] == b[2], bool((a[4] == b[4]).all())]
     ok = all(same)
-    desc = dict(it=it, bits=bits, k=k, h=h, L=L, n_reads=n_reads, counting=bool(counting), ragged=bool(ragged), scratch=scratch)
+    desc = dict(it=it, bits=bits, k=k, h=h, L=L, n_reads=n_reads, counting=bool(counting), ragged=bool(ragged), scratch=scratch,
+                spaced=bool(seeds))
     if not ok:
         print("MISMATCH (filter, hits, counts, valid) =", same, desc, a[2], b[2], flush=True)
     return ok, desc
