@@ -139,3 +139,45 @@ def test_insert_and_contains_file(tmp_path, oracle, batch):
     f.insertFile(files["fasta"][0])
     q = f.containsFile(other)
     assert q["n_windows"] == 5000 - k + 1 and q["n_hits"] < 20
+
+
+def test_parser_random_files(tmp_path):
+    """seeded random FASTA / FASTQ / plain files (wrap widths, CRLF, blank lines, empty records, missing
+    final newline) at random batch sizes: every window of every sequence comes out exactly once"""
+    import btl_bloomfilter_amd as m
+
+    rng = random.Random(2024)
+    for case in range(120):
+        kind = rng.choice(["fasta", "fastq", "plain"])
+        k = rng.choice([1, 3, 11, 31])
+        crlf = rng.random() < 0.3
+        nl = "\r\n" if crlf else "\n"
+        seqs = [_rand_seq(rng, rng.choice([0, 1, 2, k - 1, k, k + 1, 40, 90, 400]), with_n=rng.random() < 0.5)
+                for _ in range(rng.randrange(1, 12))]
+        lines, per_line = [], []
+        for i, s in enumerate(seqs):
+            if kind == "fasta":
+                lines.append(">s%d" % i)
+                if rng.random() < 0.2:
+                    lines.append("")
+                for piece in _wrap(s, rng.choice([7, 60, 1000])):
+                    lines.append(piece)
+                    if piece:
+                        per_line.append(piece)
+            elif kind == "fastq":
+                lines += ["@q%d" % i, s, "+", "".join(rng.choice("@>+#I") for _ in s)]
+                if s:
+                    per_line.append(s)
+            else:
+                if s:  # a blank line is no sequence
+                    lines.append(s)
+                    per_line.append(s)
+        text = nl.join(lines) + (nl if rng.random() < 0.7 else "")
+        path = tmp_path / ("f%d" % case)
+        path.write_bytes(text.encode())
+        recs = [s for s in seqs if s]
+        for lines_mode in (False, True):
+            want = per_line if (lines_mode and kind == "fasta") else (recs if kind != "plain" else per_line)
+            batch = rng.choice([0, 4 * k + 64, 4 * k + 64 + rng.randrange(1, 50), 977, 1 << 14])
+            got = rebuild(list(m.fastx_batches(path, k, per_line=lines_mode, batch_bytes=batch)), k)
+            assert windows(got, k) == windows(want, k), (case, kind, k, crlf, lines_mode, batch)
