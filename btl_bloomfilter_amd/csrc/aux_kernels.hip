@@ -356,4 +356,55 @@ hipError_t launch_and_answers(const uint64_t* tags, const uint8_t* answers, uint
 	return hipGetLastError();
 }
 
+// ---- per-sequence totals of a per-window bitmap (what read classifiers consume) --------------------
+// set bits of `bits` in window range [lo, hi) (bit p of the bitmap = window starting at byte p)
+__device__ __forceinline__ uint32_t popc_range(const uint64_t* bits, uint64_t lo, uint64_t hi)
+{
+	if (hi <= lo)
+		return 0;
+	uint32_t n = 0;
+	const uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+	for (uint64_t w = w0; w <= w1; ++w) {
+		uint64_t x = bits[w];
+		if (w == w0)
+			x &= ~0ull << (lo & 63);
+		if (w == w1 && ((hi & 63) != 0))
+			x &= ~0ull >> (64 - (hi & 63));
+		n += __popcll(x);
+	}
+	return n;
+}
+
+__global__ __launch_bounds__(256) void count_per_seq_kernel(const uint64_t* hit_bits, const uint64_t* valid_bits,
+                                                            uint64_t len, const uint64_t* starts, uint64_t n_seqs,
+                                                            uint32_t read_len, uint32_t k, uint32_t* hits_out,
+                                                            uint32_t* valid_out)
+{
+	for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_seqs;
+	     s += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t b = starts ? starts[s] : s * read_len;
+		uint64_t e = starts ? starts[s + 1] : b + read_len;
+		if (e > len)
+			e = len;
+		const uint64_t hi = e >= b + k ? e - k + 1 : b; // windows of this sequence start in [b, hi)
+		hits_out[s] = popc_range(hit_bits, b, hi);
+		if (valid_out)
+			valid_out[s] = valid_bits ? popc_range(valid_bits, b, hi) : (uint32_t)(hi - b);
+	}
+}
+
+hipError_t launch_count_per_seq(const uint64_t* hit_bits, const uint64_t* valid_bits, uint64_t len,
+                                const uint64_t* starts, uint64_t n_seqs, uint32_t read_len, uint32_t k,
+                                uint32_t* hits_out, uint32_t* valid_out, hipStream_t s)
+{
+	if (n_seqs == 0)
+		return hipSuccess;
+	uint64_t blocks = (n_seqs + 255) / 256;
+	if (blocks > 65536)
+		blocks = 65536;
+	hipLaunchKernelGGL(count_per_seq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, hit_bits, valid_bits, len, starts,
+	                   n_seqs, read_len, k, hits_out, valid_out);
+	return hipGetLastError();
+}
+
 } // namespace btlbf

@@ -1985,6 +1985,59 @@ extern "C" int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, u
 	return BTLBF_OK;
 }
 
+extern "C" int btlbf_count_per_seq(const uint64_t* hit_bits, const uint64_t* valid_bits, uint64_t len,
+                                   const btlbf_layout* layout, unsigned kmer_size, uint32_t* hits_out,
+                                   uint32_t* valid_out, int mem, int device, void* stream)
+{
+	if (!layout || (!layout->starts && !layout->read_len))
+		return fail(BTLBF_EINVAL, "count_per_seq needs a layout (starts[] or read_len)");
+	if (kmer_size == 0 || (len && (!hit_bits || !hits_out)))
+		return fail(BTLBF_EINVAL, "null argument");
+	int rc = check_layout(layout, len);
+	if (rc)
+		return rc;
+	const uint64_t n_seqs = layout->starts ? layout->n_seqs : len / layout->read_len;
+	if (n_seqs == 0)
+		return BTLBF_OK;
+	if (mem != BTLBF_HOST && mem != BTLBF_DEVICE)
+		return fail(BTLBF_EINVAL, "mem must be BTLBF_HOST or BTLBF_DEVICE");
+	DeviceGuard g(device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const size_t bm = bitmap_bytes(len);
+	DevBuf d_hit, d_valid, d_starts, d_ho, d_vo;
+	const uint64_t *ph = hit_bits, *pv = valid_bits, *ps = layout->starts;
+	uint32_t *po = hits_out, *pvo = valid_out;
+	if (mem == BTLBF_HOST) {
+		HIP_TRY(d_hit.alloc(bm));
+		HIP_TRY(hipMemcpyAsync(d_hit.p, hit_bits, bm, hipMemcpyHostToDevice, s));
+		ph = d_hit.as<uint64_t>();
+		if (valid_bits) {
+			HIP_TRY(d_valid.alloc(bm));
+			HIP_TRY(hipMemcpyAsync(d_valid.p, valid_bits, bm, hipMemcpyHostToDevice, s));
+			pv = d_valid.as<uint64_t>();
+		}
+		if (layout->starts) {
+			HIP_TRY(d_starts.alloc((n_seqs + 1) * 8));
+			HIP_TRY(hipMemcpyAsync(d_starts.p, layout->starts, (n_seqs + 1) * 8, hipMemcpyHostToDevice, s));
+			ps = d_starts.as<uint64_t>();
+		}
+		HIP_TRY(d_ho.alloc(n_seqs * 4));
+		po = d_ho.as<uint32_t>();
+		if (valid_out) {
+			HIP_TRY(d_vo.alloc(n_seqs * 4));
+			pvo = d_vo.as<uint32_t>();
+		}
+	}
+	HIP_TRY(launch_count_per_seq(ph, pv, len, ps, n_seqs, layout->starts ? 0 : layout->read_len, kmer_size, po, pvo, s));
+	if (mem == BTLBF_HOST) {
+		HIP_TRY(hipMemcpyAsync(hits_out, po, n_seqs * 4, hipMemcpyDeviceToHost, s));
+		if (valid_out)
+			HIP_TRY(hipMemcpyAsync(valid_out, pvo, n_seqs * 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+	}
+	return BTLBF_OK;
+}
+
 extern "C" int btlbf_popcount_bits(const void* dev_buf, uint64_t nbytes, uint64_t* out, int device,
                                    void* stream)
 {

@@ -192,6 +192,9 @@ hipError_t launch_microbench(void* data, uint64_t nbytes, int kind, uint64_t n_a
                              unsigned long long* sink, hipStream_t s);
 hipError_t launch_positions(int test, void* filter, const ModParams& mod, const uint64_t* pos,
                             uint64_t n, uint8_t* out, hipStream_t s);
+hipError_t launch_count_per_seq(const uint64_t* hit_bits, const uint64_t* valid_bits, uint64_t len,
+                                const uint64_t* starts, uint64_t n_seqs, uint32_t read_len, uint32_t k,
+                                uint32_t* hits_out, uint32_t* valid_out, hipStream_t s);
 hipError_t launch_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, uint32_t h,
                               uint64_t* hit_bits, hipStream_t s);
 

@@ -489,6 +489,29 @@ def synth_reads_device(seed, first, n_reads, read_len, device=0, stream=None):
     return out
 
 
+def count_per_seq(hit_bits, valid_bits, n_bytes, k, starts=None, read_len=0, device=0, stream=None):
+    """per-sequence (hits, clean windows) from the per-window bitmaps of containsSeqs / insertAndCheckSeqs
+    over a buffer of n_bytes bytes (btlbf_count_per_seq): what a read classifier needs per read"""
+    hb = _Buf(hit_bits, np.uint64)
+    lay, keep = _layout(starts, read_len, hb.mem)
+    if lay is None:
+        raise ValueError("count_per_seq needs starts or read_len")
+    n_seqs = lay.n_seqs if starts is not None else n_bytes // read_len
+    vb = _Buf(valid_bits, np.uint64) if valid_bits is not None else None
+    if hb.mem == DEVICE:
+        import torch
+
+        hits = torch.zeros(n_seqs, dtype=torch.int32, device=hb.keep.device)
+        valid = torch.zeros(n_seqs, dtype=torch.int32, device=hb.keep.device)
+        p1, p2 = C.c_void_p(hits.data_ptr()), C.c_void_p(valid.data_ptr())
+    else:
+        hits, valid = np.zeros(n_seqs, np.uint32), np.zeros(n_seqs, np.uint32)
+        p1, p2 = C.c_void_p(hits.ctypes.data), C.c_void_p(valid.ctypes.data)
+    check(_lib.load().btlbf_count_per_seq(hb.ptr, vb.ptr if vb is not None else None, int(n_bytes), C.byref(lay), int(k),
+                                           p1, p2, hb.mem, device, _stream_ptr(stream)))
+    return hits, valid
+
+
 def fastx_batches(path, k, per_line=False, batch_bytes=0, pageable=True):
     """Iterate over the parser's batches as (bases: bytes, starts: list[int]) -- the host-side reader
     behind insertFile (btlbf_fastx_open / btlbf_fastx_next); needs no GPU."""

@@ -282,6 +282,15 @@ int btlbf_synth_reads(char* dev_out, uint64_t seed, uint64_t first_read, uint64_
  * returned in *n_done; *seconds = kernel time from HIP events */
 int btlbf_microbench(btlbf_filter* f, int kind, uint64_t n_access, uint64_t* n_done, double* seconds);
 
+/* per-sequence totals of the per-window bitmaps that btlbf_contains_seqs / btlbf_insert_and_check_seqs
+ * produce: hits_out[s] = windows of sequence s whose bit is set in hit_bits, valid_out[s] (optional) =
+ * its clean windows (valid_bits == NULL: all of its len-k+1 windows).  This is what read classifiers
+ * built on the reference do per read with an ntHashIterator loop and a counter.  Device pointers
+ * (mem == BTLBF_DEVICE) or host buffers; layout as for the call that made the bitmaps. */
+int btlbf_count_per_seq(const uint64_t* hit_bits, const uint64_t* valid_bits, uint64_t len,
+                        const btlbf_layout* layout, unsigned kmer_size, uint32_t* hits_out, uint32_t* valid_out,
+                        int mem, int device, void* stream);
+
 /* ---- FASTA / FASTQ ingestion -------------------------------------------------
  * Replaces the reference's toy loaders: Tests/AdHoc/ParallelFilter.cpp:104-122 (loadBf: header line +
  * one sequence line, an ntHashIterator per line) and swig/writeBloom_rolling.cpp:18-59

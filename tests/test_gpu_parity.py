@@ -659,3 +659,39 @@ def test_partitioned_counting_increment_all_and_query(bf, nbytes, k, h):
     c.setInsertMode("partitioned")
     c.insertSeqs(reads, read_len=L)
     assert 0 < c.popCount() <= a.popCount()
+
+
+# ---------------------------------------------------------------------------------------------
+# per-read totals of the contains() bitmaps (what read classifiers built on the reference compute)
+# ---------------------------------------------------------------------------------------------
+def test_count_per_seq_matches_bitmaps(bf, oracle):
+    import torch
+
+    rng = np.random.RandomState(8)
+    k, h, bits = 21, 3, 1 << 20
+    f = bf.BloomFilter(bits, h, k)
+    # ragged, host
+    lens = [0, 5, 20, 21, 22, 150, 64, 63, 65, 1000, 0, 21]
+    reads = [rand_seq(rng, n, 0.02) for n in lens]
+    buf = b"".join(reads)
+    starts = np.cumsum([0] + lens).astype(np.uint64)
+    f.insertSeqs(np.frombuffer(b"".join(reads[::2]), np.uint8).copy(),
+                 starts=np.cumsum([0] + lens[::2]).astype(np.uint64))
+    hit, valid, _ = f.containsSeqs(np.frombuffer(buf, np.uint8).copy(), starts=starts)
+    hits, clean = bf.count_per_seq(hit, valid, len(buf), k, starts=starts)
+    hb, vb = bf.bits_to_bool(hit, len(buf)), bf.bits_to_bool(valid, len(buf))
+    for i, (a, b) in enumerate(zip(starts[:-1], starts[1:])):
+        a, b = int(a), int(b)
+        hi = max(b - k + 1, a)
+        assert hits[i] == hb[a:hi].sum() and clean[i] == vb[a:hi].sum(), i
+        assert clean[i] == len(oracle.nthash_seq(reads[i], h, k)[0])
+    assert all(hits[i] == clean[i] for i in range(0, len(lens), 2))  # the inserted reads hit everywhere
+    # uniform, device, no valid bitmap: clean = all windows
+    L, n = 150, 5000
+    dev = bf.synth_reads_device(5, 0, n, L)
+    f.insertSeqs(dev[: 1000 * L], read_len=L)
+    hit, valid, cnt = f.containsSeqs(dev, read_len=L, want_counts=True)
+    hits, clean = bf.count_per_seq(hit, None, dev.numel(), k, read_len=L)
+    torch.cuda.synchronize()
+    assert int(hits.sum().item()) == int(cnt[1].item()) and bool((clean == L - k + 1).all().item())
+    assert bool((hits[:1000] == L - k + 1).all().item()) and int(hits[1000:].max().item()) < L - k + 1
