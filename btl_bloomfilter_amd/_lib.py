@@ -104,6 +104,8 @@ _PROTOS = {
     "btlbf_microbench": (C.c_int, [_P, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "btlbf_count_per_seq": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_uint, _P, _P, C.c_int, C.c_int, _P]),
     "btlbf_fastx_open": (C.c_int, [C.POINTER(_P), C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "btlbf_fastx_open_range": (C.c_int, [C.POINTER(_P), C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
+                                         C.c_uint64, C.c_uint64]),
     "btlbf_fastx_next": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "btlbf_fastx_records": (C.c_uint64, [_P]),
     "btlbf_fastx_close": (None, [_P]),

@@ -512,13 +512,20 @@ def count_per_seq(hit_bits, valid_bits, n_bytes, k, starts=None, read_len=0, dev
     return hits, valid
 
 
-def fastx_batches(path, k, per_line=False, batch_bytes=0, pageable=True):
+def fastx_batches(path, k, per_line=False, batch_bytes=0, pageable=True, byte_range=None, fmt=None):
     """Iterate over the parser's batches as (bases: bytes, starts: list[int]) -- the host-side reader
-    behind insertFile (btlbf_fastx_open / btlbf_fastx_next); needs no GPU."""
+    behind insertFile (btlbf_fastx_open / btlbf_fastx_next); needs no GPU.  byte_range=(begin, end) with
+    fmt in {"fasta", "fastq", "plain"}: only the records that start in that byte range of an
+    uncompressed file (btlbf_fastx_open_range, the unit of parallel parsing)."""
     L = _lib.load()
     r = C.c_void_p()
     flags = (1 if per_line else 0) | (2 if pageable else 0)
-    check(L.btlbf_fastx_open(C.byref(r), str(path).encode(), flags, int(k), int(batch_bytes)))
+    if byte_range is None:
+        check(L.btlbf_fastx_open(C.byref(r), str(path).encode(), flags, int(k), int(batch_bytes)))
+    else:
+        check(L.btlbf_fastx_open_range(C.byref(r), str(path).encode(), flags, int(k), int(batch_bytes),
+                                       {"fasta": 1, "fastq": 2, "plain": 3}[fmt], int(byte_range[0]),
+                                       int(byte_range[1])))
     try:
         while True:
             b, s = C.c_void_p(), C.c_void_p()

@@ -312,6 +312,12 @@ int btlbf_fastx_open(btlbf_fastx** r, const char* path, uint32_t flags, uint32_t
  * one; n_seqs == 0 at end of input */
 int btlbf_fastx_next(btlbf_fastx* r, const char** bases, uint64_t* n_bases, const uint64_t** starts,
                      uint64_t* n_seqs);
+/* one of several readers over the same UNCOMPRESSED file (parallel parsing): delivers the records that
+ * START in byte range [begin, end); the ranges of all readers must tile the file.  fmt: 1 = FASTA,
+ * 2 = FASTQ (4-line), 3 = one sequence per line.  btlbf_insert_fastx / btlbf_contains_fastx do this
+ * internally (BTLBF_FASTX_THREADS, default min(8, cores)). */
+int btlbf_fastx_open_range(btlbf_fastx** r, const char* path, uint32_t flags, uint32_t k, uint64_t batch_bytes,
+                           int fmt, uint64_t begin, uint64_t end);
 uint64_t btlbf_fastx_records(const btlbf_fastx* r); /* records seen so far */
 void btlbf_fastx_close(btlbf_fastx* r);
 

@@ -113,9 +113,13 @@ def test_parser_errors(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch", [0, 700])
-def test_insert_and_contains_file(tmp_path, oracle, batch):
+@pytest.mark.parametrize("batch,threads", [(0, 1), (700, 1), (0, 3), (900, 5)])
+def test_insert_and_contains_file(tmp_path, oracle, batch, threads, monkeypatch):
     import btl_bloomfilter_amd as m
+
+    # threads > 1: one parser thread per byte range of the (uncompressed) file, whatever its size
+    monkeypatch.setenv("BTLBF_FASTX_THREADS", str(threads))
+    monkeypatch.setenv("BTLBF_FASTX_MT_MIN_BYTES", "0" if threads > 1 else str(1 << 40))
     rng = random.Random(11)
     files = make_files(tmp_path, rng)
     bits, h, k = 1 << 20, 3, K
@@ -181,3 +185,31 @@ def test_parser_random_files(tmp_path):
             batch = rng.choice([0, 4 * k + 64, 4 * k + 64 + rng.randrange(1, 50), 977, 1 << 14])
             got = rebuild(list(m.fastx_batches(path, k, per_line=lines_mode, batch_bytes=batch)), k)
             assert windows(got, k) == windows(want, k), (case, kind, k, crlf, lines_mode, batch)
+
+
+def test_ranged_readers_tile_the_file(tmp_path):
+    """parallel parsing: readers over byte ranges that tile the file deliver every record exactly once,
+    wherever the cuts fall (every cut position of small files, random cuts of larger ones)"""
+    import os
+
+    import btl_bloomfilter_amd as m
+
+    rng = random.Random(99)
+    files = make_files(tmp_path, rng)
+    k = K
+    for name, fmt in (("fasta", "fasta"), ("fastq", "fastq"), ("plain", "plain")):
+        path, recs, per_line = files[name]
+        size = os.path.getsize(path)
+        for lines_mode in (False, True):
+            want = windows(per_line if lines_mode else recs, k)
+            cut_sets = [[c] for c in range(0, size + 1, 1 if size < 1500 else 37)]
+            cut_sets += [sorted(rng.sample(range(size), 5)) for _ in range(20)]
+            for cuts in cut_sets:
+                edges = [0] + cuts + [size]
+                got = []
+                for a, b in zip(edges[:-1], edges[1:]):
+                    if a == b:
+                        continue
+                    got += rebuild(list(m.fastx_batches(path, k, per_line=lines_mode, batch_bytes=4096,
+                                                        byte_range=(a, b), fmt=fmt)), k)
+                assert windows(got, k) == want, (name, lines_mode, cuts)
