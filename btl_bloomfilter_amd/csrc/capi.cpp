@@ -1452,8 +1452,8 @@ struct RoutePlan {
 int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, unsigned n_shards, RoutePlan& rp)
 {
 	const uint64_t M = f->mod.size;
-	if (f->kind != BTLBF_BLOOM || !f->mod.pow2 || n_shards == 0 || (n_shards & (n_shards - 1)) || n_shards > 1024)
-		return fail(BTLBF_EINVAL, "routing needs a bit filter whose global size and shard count are powers of two");
+	if (!f->mod.pow2 || n_shards == 0 || (n_shards & (n_shards - 1)) || n_shards > 1024)
+		return fail(BTLBF_EINVAL, "routing needs a filter whose global size and shard count are powers of two");
 	if (!part_supported_h(f->hp.h) || !part_hash_fits(f->hp, 1024))
 		return fail(BTLBF_EINVAL, "routing does not support this hash configuration");
 	// 512 global level-0 bins (64-entry LDS rings at the origin: few late entries) as long as an entry
@@ -1467,8 +1467,9 @@ int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, uns
 			rp.bins = b;
 	}
 	const unsigned lm = ceil_log2(M), lb = ceil_log2(rp.bins);
-	if (lm < lb + 19 || lm - lb > 32 || rp.bins < n_shards)
-		return fail(BTLBF_EINVAL, "routing supports global filters of 2^29 .. 2^42 bits");
+	const unsigned seg_min = f->kind == BTLBF_COUNTING8 ? 16 : 19; // positions in a 64 KiB segment
+	if (lm < lb + seg_min || lm - lb > 32 || rp.bins < n_shards)
+		return fail(BTLBF_EINVAL, "routing supports global filters of 2^29 .. 2^42 bits (2^26 .. 2^42 counters)");
 	rp.shift0 = lm - lb;
 	rp.bins_per_shard = rp.bins / n_shards;
 	rp.regions = cu_count(f->device);
@@ -1568,7 +1569,7 @@ extern "C" int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const v
 	if (rc)
 		return rc;
 	PartPlan pl;
-	if (!plan_segments(f->mod.shard_len, pl))
+	if (!plan_segments(f->mod.shard_len, pl, f->kind == BTLBF_COUNTING8 ? 0 : 3))
 		return fail(BTLBF_EINVAL, "shard too large for the partitioned pipeline");
 	pl.lv[0].bins = rp.bins_per_shard;
 	pl.lv[0].shift = rp.shift0;
@@ -1591,6 +1592,8 @@ extern "C" int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const v
 	sd.fail_list = fail_list;
 	sd.fail_count = reinterpret_cast<unsigned long long*>(fail_count);
 	sd.fail_cap = fail_cap;
+	sd.counting = f->kind == BTLBF_COUNTING8; // incrementAll / counter >= threshold at the owner
+	sd.threshold = f->thr;
 	PartIn in0{n_blocks, rp.bins_per_shard, rp.regions, rp.cap, static_cast<const uint32_t*>(recv_cnt),
 	           static_cast<const uint32_t*>(recv_ent)};
 	return run_levels(f, pl, in0, sd, query, s);
@@ -1601,14 +1604,14 @@ extern "C" int btlbf_apply_spill(btlbf_filter* f, const uint64_t* global_pos, ui
 {
 	if (!f || (n && !global_pos))
 		return fail(BTLBF_EINVAL, "null argument");
-	if (f->kind != BTLBF_BLOOM)
-		return fail(BTLBF_EINVAL, "bit filters only");
 	DeviceGuard g(f->device);
 	PartSide sd;
 	memset(&sd, 0, sizeof sd);
 	sd.fail_list = fail_list;
 	sd.fail_count = reinterpret_cast<unsigned long long*>(fail_count);
 	sd.fail_cap = fail_cap;
+	sd.counting = f->kind == BTLBF_COUNTING8;
+	sd.threshold = f->thr;
 	HIP_TRY(launch_spill(f->d_data, global_pos, n, f->mod.shard_lo, f->mod.shard_len, query, sd,
 	                     static_cast<hipStream_t>(stream)));
 	return BTLBF_OK;

@@ -464,10 +464,16 @@ __global__ __launch_bounds__(256) void spill_kernel(uint32_t* words, const uint6
 		const uint64_t lp = pos[i] - lo;
 		if (lp >= len)
 			continue;
-		if (!test)
+		if (sd.counting) {
+			if (!test)
+				cbf_inc_sat(words, lp);
+			else if (cbf_read_fresh(words, lp) < sd.threshold)
+				part_report_fail(sd, pos[i]);
+		} else if (!test) {
 			bf_set(words, lp);
-		else if (!((bf_word(words, lp) >> (lp & 31)) & 1u))
+		} else if (!((bf_word(words, lp) >> (lp & 31)) & 1u)) {
 			part_report_fail(sd, pos[i]);
+		}
 	}
 }
 

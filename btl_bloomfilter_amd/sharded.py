@@ -35,16 +35,18 @@ from . import _lib
 class HipShardOps:
     """per-rank compute through the C ABI (HIP kernels); tensors live on cuda:<device>"""
 
-    def __init__(self, global_bits, hash_num, kmer_size, rank, world, device):
+    def __init__(self, global_bits, hash_num, kmer_size, rank, world, device, counting=False, threshold=0):
+        """global_bits: bits of the whole filter, or its uint8_t counters when counting"""
         self.L = _lib.load()
         self.h = hash_num
         self.k = kmer_size
         self.world = world
+        self.counting = bool(counting)
         self.device_index = device
         self.device = torch.device("cuda", device)
         hnd = C.c_void_p()
-        _lib.check(self.L.btlbf_create_shard(C.byref(hnd), _lib.BLOOM, global_bits, rank, world, hash_num,
-                                             kmer_size, 0, device))
+        _lib.check(self.L.btlbf_create_shard(C.byref(hnd), _lib.COUNTING8 if counting else _lib.BLOOM, global_bits,
+                                             rank, world, hash_num, kmer_size, threshold, device))
         self.f = hnd
 
     def close(self):
@@ -105,7 +107,8 @@ class HipShardOps:
 
     def route_supported(self, global_bits, world):
         pow2 = lambda x: x > 0 and (x & (x - 1)) == 0  # noqa: E731
-        return pow2(global_bits) and pow2(world) and (1 << 29) <= global_bits <= (1 << 42) and 1 <= self.h <= 8
+        lo = 1 << (26 if self.counting else 29)  # 512 bins of at least one 64 KiB segment
+        return pow2(global_bits) and pow2(world) and lo <= global_bits <= (1 << 42) and 1 <= self.h <= 8
 
     def route_plan(self, plan_len, read_len):
         e, c = C.c_uint64(), C.c_uint64()
@@ -153,8 +156,13 @@ class HipShardOps:
 
 
 class ShardedBloomFilter:
+    """counting=True: a sharded CountingBloomFilter<uint8_t> of `global_bits` counters -- insert_reads is
+    incrementAll (exact, saturating; shard-local at the owners) and contains_reads is
+    "minimum >= threshold"; routed path only (the conservative update needs the h counters of a k-mer,
+    which live on different shards, and is not offered)."""
+
     def __init__(self, global_bits, hash_num, kmer_size, device=0, group=None, ops=None, batch_reads=2_000_000,
-                 slack=1.25, route=True, batch_bytes_cap=0, pipeline=None):
+                 slack=1.25, route=True, batch_bytes_cap=0, pipeline=None, counting=False, threshold=0):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -163,8 +171,11 @@ class ShardedBloomFilter:
         self.bits = global_bits
         self.h = hash_num
         self.k = kmer_size
+        self.counting = bool(counting)
         self.ops = ops if ops is not None else HipShardOps(global_bits, hash_num, kmer_size, self.rank, self.world,
-                                                           device)
+                                                           device, counting=counting, threshold=threshold)
+        if self.counting and not (route and self.ops.route_supported(global_bits, self.world)):
+            raise ValueError("sharded counting filters need the routed path (power-of-two geometry, h <= 8)")
         self.batch_reads = batch_reads
         self.slack = slack
         self.route_enabled = route         # use the partitioned routing path when the geometry allows
@@ -388,6 +399,8 @@ class ShardedBloomFilter:
             if not self._routed_pass(reads, read_len, 0):
                 raise RuntimeError("routed insert: spill list overflow")
             return
+        if self.counting:
+            raise RuntimeError("counting filters have no direct exchange path")
         for _, chunk in self._batches(reads, read_len):
             send, _, cnt, recv_cnt, _ = self._bucketed(chunk, read_len, False)
             mine = self._all_to_all(send, cnt, recv_cnt)
@@ -400,6 +413,8 @@ class ShardedBloomFilter:
             if self._routed_pass(reads, read_len, 1, hit_bits, counts):
                 return hit_bits
             # too many failed probes for the fail lists: fall through to the exact answer routing
+            if self.counting:
+                raise RuntimeError("counting query: more failed probes than the fail lists hold")
         n_valid = n_hit = 0
         for off, chunk in self._batches(reads, read_len):
             send, stags, cnt, recv_cnt, valid = self._bucketed(chunk, read_len, True)

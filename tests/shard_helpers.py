@@ -183,3 +183,44 @@ def free_port():
 
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gpu_worker_counting(rank, world, port, outdir, counters, h, k, thr, n_reads, read_len):
+    """sharded CountingBloomFilter (incrementAll + contains) on the routed path, all ranks on cuda:0"""
+    import btl_bloomfilter_amd as m
+    from btl_bloomfilter_amd.sharded import ShardedBloomFilter
+
+    torch.cuda.set_device(0)
+    _init(rank, world, port)
+    f = ShardedBloomFilter(counters, h, k, device=0, batch_bytes_cap=4 << 20, pipeline=True, counting=True,
+                           threshold=thr)
+    mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
+    f.insert_reads(mine, read_len)
+    f.insert_reads(mine[: (n_reads // 2) * read_len], read_len)  # half of the reads a second time
+    torch.cuda.synchronize()
+    dist.barrier()
+    np.save(os.path.join(outdir, "body%d.npy" % rank), f.ops.local_body())
+    # reference: the whole counting filter on this GPU, direct kernels, the same multiset of reads
+    ref = m.CountingBloomFilter(counters, h, k, thr)
+    ref.setInsertMode("direct")
+    ref.setQueryMode("direct")
+    for r in range(world):
+        rr = m.synth_reads_device(42, r * n_reads, n_reads, read_len)
+        ref.insertSeqs(rr, read_len=read_len, increment_all=True)
+        ref.insertSeqs(rr[: (n_reads // 2) * read_len], read_len=read_len, increment_all=True)
+    # mostly reads inserted twice (pass the threshold), a few inserted once and a few foreign ones
+    half = (n_reads // 2) * read_len
+    q = torch.cat([mine[: half + 50 * read_len], m.synth_reads_device(43, rank * 20, 20, read_len)])
+    hit = torch.zeros((q.numel() + 63) // 64, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int64)
+    f.contains_reads(q, read_len, hit, cnt)
+    eh, _, ec = ref.containsSeqs(q, read_len=read_len, want_valid=False, want_counts=True)
+    torch.cuda.synchronize()
+    res = (bool((hit == eh).all().item()), cnt.tolist(), ec.cpu().tolist())
+    np.save(os.path.join(outdir, "res%d.npy" % rank), np.array([repr(res)]))
+    f.store(os.path.join(outdir, "sharded.bf"))  # every rank writes its counter range into the one file
+    if rank == 0:
+        np.save(os.path.join(outdir, "ref.npy"), ref.download())
+        ref.storeFilter(os.path.join(outdir, "ref.bf"))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -11,7 +11,7 @@ import pytest
 import torch.multiprocessing as mp
 
 from conftest import load_golden
-from shard_helpers import cpu_worker, free_port, gpu_worker, gpu_worker_routed, sha
+from shard_helpers import cpu_worker, free_port, gpu_worker, gpu_worker_counting, gpu_worker_routed, sha
 
 
 def expected(oracle, bits, h, k, world, n_reads, L):
@@ -175,3 +175,21 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["kmers_per_pass"] == 2 * 200000 * 120
+
+
+@pytest.mark.gpu
+def test_sharded_counting_filter_two_ranks_one_gpu(tmp_path):
+    """the counting filter shards like the bit filter -- incrementAll is shard-local at the
+    owners and exact (saturating), contains() = minimum >= threshold; against one unsharded filter"""
+    counters, h, k, thr, L, world, n_reads = 1 << 28, 3, 25, 2, 150, 2, 40000
+    mp.spawn(gpu_worker_counting, args=(world, free_port(), str(tmp_path), counters, h, k, thr, n_reads, L),
+             nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+    ref = np.load(tmp_path / "ref.npy")
+    assert got.shape == ref.shape and (got == ref).all() and got.max() >= 2
+    # the file the shards wrote together is the unsharded filter's file, byte for byte
+    assert open(tmp_path / "sharded.bf", "rb").read() == open(tmp_path / "ref.bf", "rb").read()
+    for rank in range(world):
+        same, cnt, exp = eval(str(np.load(tmp_path / ("res%d.npy" % rank))[0]))
+        assert same and cnt == exp, (rank, cnt, exp)
+        assert (n_reads // 2) * (L - k + 1) <= cnt[1] < cnt[0]
