@@ -171,24 +171,35 @@ __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, u
 
 	// words past the data are zero-filled so no stale flags survive
 	auto convert = [&](uint32_t j, uint32_t raw) {
-		// position of this word's first byte relative to g0 (negative for the misaligned head)
+		// position of this word's first byte relative to g0 (negative for the misaligned head); bytes
+		// outside [0, need) are zeroed with one mask per word
 		const int32_t rel0 = (int32_t)(4 * j) - (int32_t)mis;
-		uint32_t r = 0; // offset within its read of the word's first byte (uniform layout only)
-		if (uniform)
-			r = small_mod(tile_off + 4 * j + 4 * L - mis, L, inv);
-		uint32_t o = 0;
+		const int32_t lo = rel0 < 0 ? (-rel0 < 4 ? -rel0 : 4) : 0; // leading bytes before the data
+		const int64_t left = (int64_t)need - rel0;                  // bytes of data from this word on
+		const int32_t hi = left <= 0 ? 0 : (left < 4 ? (int32_t)left : 4);
+		uint32_t keep = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1);
+		if (lo)
+			keep &= lo >= 4 ? 0u : ~((1u << (8 * lo)) - 1);
+		uint32_t o = (uint32_t)sh.lut[raw & 0xff] | ((uint32_t)sh.lut[(raw >> 8) & 0xff] << 8) |
+		             ((uint32_t)sh.lut[(raw >> 16) & 0xff] << 16) | ((uint32_t)sh.lut[raw >> 24] << 24);
+		o &= keep;
+		if (uniform) {
+			// offset of the word's first byte inside its read; a read of >= 4 bases starts at most once
+			// inside a word, at byte (L - r) % L
+			const uint32_t r = small_mod(tile_off + 4 * j + 4 * L - mis, L, inv);
+			if (L >= 4) {
+				const uint32_t bstar = r ? L - r : 0;
+				if (bstar < 4)
+					o &= ~(kBaseGood << (8 * bstar));
+			} else {
+				uint32_t rr = r;
 #pragma unroll
-		for (int b = 0; b < 4; ++b) {
-			const int32_t rel = rel0 + b;
-			uint32_t e = sh.lut[(raw >> (8 * b)) & 0xff];
-			if (rel < 0 || (uint64_t)rel >= need)
-				e = 0;
-			if (uniform) {
-				if (r == 0)
-					e &= ~kBaseGood;
-				r = (r + 1 == L) ? 0 : r + 1;
+				for (int b = 0; b < 4; ++b) {
+					if (rr == 0)
+						o &= ~(kBaseGood << (8 * b));
+					rr = (rr + 1 == L) ? 0 : rr + 1;
+				}
 			}
-			o |= e << (8 * b);
 		}
 		reinterpret_cast<uint32_t*>(tile)[j] = o;
 	};
