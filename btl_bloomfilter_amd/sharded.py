@@ -189,6 +189,12 @@ class ShardedBloomFilter:
         self.stage_cpu = backend == "gloo"
 
     # ---- the exchange -----------------------------------------------------------------------
+    # No single point-to-point message is larger than this.  Measured on this stack (ROCm 7.2 RCCL,
+    # examples/sharded_rccl.cpp): a grouped ncclSend/ncclRecv of more than about 1 GiB delivered only
+    # half of its bytes (973 MB arrives whole, 2.0 GB and 4.2 GB arrive halved), so large blocks are
+    # exchanged as a sequence of grouped all-to-alls over slices.
+    MSG_BYTES = 256 << 20
+
     def _all_to_all(self, send, send_counts, recv_counts):
         """variable-size all-to-all of a flat tensor; counts are python ints per peer"""
         if self.world == 1:
@@ -197,8 +203,29 @@ class ShardedBloomFilter:
         if self.stage_cpu and send.is_cuda:
             send = send.cpu()
         recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=send.device)
-        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                               group=self.group)
+        step = max(1, self.MSG_BYTES // send.element_size())
+        rounds = self._max_over_ranks(-(-max(max(send_counts), max(recv_counts), 1) // step))
+        if rounds <= 1:
+            dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                   group=self.group)
+        else:
+            so = [0] + list(torch.tensor(send_counts).cumsum(0).tolist())
+            ro = [0] + list(torch.tensor(recv_counts).cumsum(0).tolist())
+            for r in range(rounds):
+                ins = [send[so[p] + min(r * step, send_counts[p]): so[p] + min((r + 1) * step, send_counts[p])]
+                       for p in range(self.world)]
+                outs = [recv[ro[p] + min(r * step, recv_counts[p]): ro[p] + min((r + 1) * step, recv_counts[p])]
+                        for p in range(self.world)]
+                if self.stage_cpu:  # gloo (tests): the single-tensor form on the packed slices
+                    tmp = torch.empty(sum(o.numel() for o in outs), dtype=send.dtype)
+                    dist.all_to_all_single(tmp, torch.cat(ins), output_split_sizes=[o.numel() for o in outs],
+                                           input_split_sizes=[i.numel() for i in ins], group=self.group)
+                    at = 0
+                    for o in outs:
+                        o.copy_(tmp[at: at + o.numel()])
+                        at += o.numel()
+                else:
+                    dist.all_to_all(outs, ins, group=self.group)
         return recv.to(dev) if recv.device != dev else recv
 
     def _exchange_counts(self, counts):
@@ -259,8 +286,29 @@ class ShardedBloomFilter:
         if self.stage_cpu and send.is_cuda:
             send = send.cpu()
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
+        for w in self._sliced_all_to_all(recv, send, async_op=False):
+            pass
         return recv.to(dev) if recv.device != dev else recv
+
+    def _sliced_all_to_all(self, recv, send, async_op):
+        """all-to-all of equal per-peer blocks, at most MSG_BYTES per message; returns the work handles"""
+        per = send.numel() // self.world
+        step = max(1, self.MSG_BYTES // send.element_size())
+        if per <= step:
+            return [dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)]
+        s2, r2 = send.view(self.world, per), recv.view(self.world, per)
+        works = []
+        for c0 in range(0, per, step):
+            c1 = min(c0 + step, per)
+            if self.stage_cpu:  # gloo (tests): contiguous copies of the slice through the single-tensor form
+                tmp = torch.empty((self.world, c1 - c0), dtype=send.dtype)
+                dist.all_to_all_single(tmp, s2[:, c0:c1].contiguous(), group=self.group)
+                r2[:, c0:c1] = tmp
+            else:
+                works.append(dist.all_to_all([r2[p, c0:c1] for p in range(self.world)],
+                                             [s2[p, c0:c1] for p in range(self.world)], group=self.group,
+                                             async_op=async_op))
+        return works
 
     def _all_gather_var(self, t, n):
         """all-gather the first n elements of the 1-D int64 tensor t from every rank -> 1-D tensor"""
@@ -316,7 +364,7 @@ class ShardedBloomFilter:
             return None
         wide = send.numel() % (8 * self.world) == 0  # 8-byte elements keep per-peer counts below 2^31
         a, b = (recv.view(torch.int64), send.view(torch.int64)) if wide else (recv, send)
-        return dist.all_to_all_single(a, b, group=self.group, async_op=True)
+        return self._sliced_all_to_all(a, b, async_op=True)
 
     def _routed_pass(self, reads, read_len, query, hit_bits=None, counts=None):
         """One insert / query pass over this rank's reads on the routed path.  Per batch: route (pass A
@@ -346,9 +394,10 @@ class ShardedBloomFilter:
 
         def finish(p):
             slot, works = p
-            for w in works:
-                if w is not None:
-                    w.wait()  # RCCL: the compute stream waits, the host does not
+            for ws in works:
+                for w in (ws or ()):
+                    if w is not None:
+                        w.wait()  # RCCL: the compute stream waits, the host does not
             ops.apply_routed(recv_ent[slot], recv_cnt[slot], W, batch, read_len, query, fail, fail_count)
 
         pending = None

@@ -91,6 +91,8 @@ def cpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
     o = Oracle()
     ops = OracleShardOps(bits, h, k, rank, world)
     f = ShardedBloomFilter(bits, h, k, ops=ops, batch_reads=64)
+    if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
+        f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
     mine = torch.from_numpy(o.synth_reads(42, rank * n_reads, n_reads, read_len))
     f.insert_reads(mine, read_len)
     dist.barrier()
@@ -115,6 +117,8 @@ def gpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
     torch.cuda.set_device(0)
     _init(rank, world, port)
     f = ShardedBloomFilter(bits, h, k, device=0, batch_reads=4096)
+    if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
+        f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
     mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
     f.insert_reads(mine, read_len)
     torch.cuda.synchronize()
@@ -143,6 +147,8 @@ def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, 
     _init(rank, world, port)
     # several batches; pipeline=True runs the double-buffered schedule of the RCCL path over gloo
     f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=4 << 20, pipeline=pipeline)
+    if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
+        f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
     assert f._routed()
     mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
     f.insert_reads(mine, read_len)
@@ -194,6 +200,8 @@ def gpu_worker_counting(rank, world, port, outdir, counters, h, k, thr, n_reads,
     _init(rank, world, port)
     f = ShardedBloomFilter(counters, h, k, device=0, batch_bytes_cap=4 << 20, pipeline=True, counting=True,
                            threshold=thr)
+    if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
+        f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
     mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
     f.insert_reads(mine, read_len)
     f.insert_reads(mine[: (n_reads // 2) * read_len], read_len)  # half of the reads a second time

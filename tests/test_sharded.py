@@ -37,7 +37,12 @@ def check_queries(oracle, body, bits, h, k, world, n_reads, L, outdir):
         assert eh[: n_reads * L].sum() == n_reads * (L - k + 1)  # own reads: no false negatives
 
 
-def test_sharded_routing_gloo_cpu(oracle, tmp_path):
+@pytest.mark.parametrize("msg_bytes", [None, 4096])
+def test_sharded_routing_gloo_cpu(oracle, tmp_path, msg_bytes, monkeypatch):
+    # msg_bytes: the largest single message of the exchange -- small enough here that every all-to-all
+    # is cut into several rounds of slices (what protects real runs from > 1 GiB messages)
+    if msg_bytes:
+        monkeypatch.setenv("BTLBF_TEST_MSG_BYTES", str(msg_bytes))
     bits, h, k, world, n_reads, L = 1 << 16, 4, 31, 2, 128, 150
     mp.spawn(cpu_worker, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L), nprocs=world, join=True)
     body = expected(oracle, bits, h, k, world, n_reads, L)
@@ -88,7 +93,7 @@ def test_sharded_hip_two_ranks_one_gpu(oracle, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pipeline", [None, True])
-def test_sharded_routed_partitioned_two_ranks_one_gpu(tmp_path, pipeline):
+def test_sharded_routed_partitioned_two_ranks_one_gpu(tmp_path, pipeline, monkeypatch):
     """routed path: pass A per origin, fixed-size exchange of 4-byte entries, owner splits + LDS apply;
     queries return only failed positions.  Checked against the reference's golden digest and against
     the single-GPU direct kernels (all-hit, few-miss and miss-heavy queries)."""
@@ -96,7 +101,10 @@ def test_sharded_routed_partitioned_two_ranks_one_gpu(tmp_path, pipeline):
     bits, h, k, L, world = g["bits"], g["h"], g["k"], g["read_len"], 2
     n_reads = g["n_reads"] // world
     # pipeline=True: the schedule of the RCCL path (exchange of batch i in flight while batch i+1 is
-    # routed, two buffer sets, deferred apply) over the synchronous test exchange
+    # routed, two buffer sets, deferred apply) over the synchronous test exchange, and every block
+    # exchanged in slices of 16 MiB
+    if pipeline:
+        monkeypatch.setenv("BTLBF_TEST_MSG_BYTES", str(16 << 20))
     mp.spawn(gpu_worker_routed, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L, 0, pipeline),
              nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
