@@ -184,6 +184,11 @@ class ShardedBloomFilter:
         # sets).  None = whenever the exchange is asynchronous (RCCL); True forces the same schedule
         # over a synchronous exchange (tests).
         self.pipeline = pipeline
+        # BTLBF_FORCE_EXCHANGE=1: run the routed path's exchange even with a single rank (a one-rank RCCL
+        # group sends every block to itself) -- lets a one-GPU box exercise the real collective calls
+        import os as _os
+
+        self.force_exchange = bool(_os.environ.get("BTLBF_FORCE_EXCHANGE")) and dist.is_initialized()
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         # gloo moves host memory: stage device tensors through the CPU (test mode only)
         self.stage_cpu = backend == "gloo"
@@ -344,7 +349,7 @@ class ShardedBloomFilter:
         free = -self._max_over_ranks(-free)  # the smallest over ranks: every rank must plan the same batch
         # per read byte: h*(L-k+1)/L probes * 4 B per entry, ~1.1x capacity; block sets: send (+ receive
         # when there are peers), n_slots of each, + the owner's split levels, which hold 1/8 of a batch
-        sets = n_slots * (2 if self.world > 1 else 1) + 0.4
+        sets = n_slots * (2 if self.world > 1 or self.force_exchange else 1) + 0.4
         per_byte = self.h * max(read_len - self.k + 1, 1) / read_len * 4 * 1.1 * sets
         batch = int(0.7 * free / per_byte) // (64 * read_len) * (64 * read_len)
         batch = max(batch, 64 * read_len)
@@ -357,7 +362,7 @@ class ShardedBloomFilter:
         """fixed-size all-to-all of a uint8 block set.  RCCL: asynchronous on the communicator's stream
         (returns the work handle; the compute stream goes on with the next batch); gloo (test mode):
         synchronous through host memory; one rank: recv is send."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return None
         if self.stage_cpu:
             recv.copy_(self._fixed_all_to_all(send))
@@ -373,7 +378,8 @@ class ShardedBloomFilter:
         nothing in the loop waits on the host.  Spill and fail lists accumulate over the pass and are
         dealt with once at its end."""
         ops, W, dev = self.ops, self.world, self.ops.device
-        pipelined = W > 1 and (not self.stage_cpu if self.pipeline is None else bool(self.pipeline))
+        exchanging = W > 1 or self.force_exchange
+        pipelined = exchanging and (not self.stage_cpu if self.pipeline is None else bool(self.pipeline))
         batch, n_batches = self._route_batch_bytes(reads, read_len, 2 if pipelined else 1)
         if n_batches == 0:
             return True
@@ -381,7 +387,7 @@ class ShardedBloomFilter:
         n_slots = 2 if pipelined else 1
         send_ent = [torch.empty(W * ent_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
         send_cnt = [torch.empty(W * cnt_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
-        if W > 1:
+        if exchanging:
             recv_ent = [torch.empty_like(t) for t in send_ent]
             recv_cnt = [torch.empty_like(t) for t in send_cnt]
         else:

@@ -8,6 +8,8 @@ import os
 
 import numpy as np
 import pytest
+import torch
+import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import load_golden
@@ -201,3 +203,38 @@ def test_sharded_counting_filter_two_ranks_one_gpu(tmp_path):
         same, cnt, exp = eval(str(np.load(tmp_path / ("res%d.npy" % rank))[0]))
         assert same and cnt == exp, (rank, cnt, exp)
         assert (n_reads // 2) * (L - k + 1) <= cnt[1] < cnt[0]
+
+
+def _nccl_one_rank_worker(rank, port, outdir):
+    import btl_bloomfilter_amd as m
+    from btl_bloomfilter_amd.sharded import ShardedBloomFilter
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BTLBF_FORCE_EXCHANGE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    bits, h, k, L, n = 1 << 33, 4, 31, 150, 1_500_000
+    f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=80 << 20)  # three batches, pipelined
+    f.MSG_BYTES = 64 << 20  # several slices per block
+    reads = m.synth_reads_device(42, 0, n, L)
+    f.insert_reads(reads, L)
+    hit = torch.zeros((reads.numel() + 63) // 64, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int64)
+    q = torch.cat([reads[: 1000 * L], m.synth_reads_device(43, 0, 30, L)])
+    f.contains_reads(q, L, hit[: (q.numel() + 63) // 64], cnt)
+    ref = m.BloomFilter(bits, h, k)
+    ref.insertSeqs(reads, read_len=L)
+    eh, _, ec = ref.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    torch.cuda.synchronize()
+    ok = bool((torch.from_numpy(f.ops.local_body()) == torch.from_numpy(ref.download())).all())
+    same = bool((hit[: (q.numel() + 63) // 64] == eh).all().item())
+    np.save(os.path.join(outdir, "nccl1.npy"), np.array([ok, same, cnt.tolist() == ec.cpu().tolist()]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_routed_path_over_rccl_with_one_rank(tmp_path):
+    """the production exchange calls (torch.distributed on RCCL: grouped all-to-all of slices, async
+    work handles, stream waits, the double-buffered schedule) with a one-rank group: every block
+    travels GPU -> RCCL -> same GPU.  Bodies and query results against the plain filter."""
+    mp.spawn(_nccl_one_rank_worker, args=(free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert np.load(tmp_path / "nccl1.npy").all()
