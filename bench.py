@@ -196,6 +196,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif os.environ.get("BTLBF_FORCE_EXCHANGE") and os.environ.get("BTLBF_BENCH_FORCE_SHARDED"):
+        # one GPU, but with the exchange of the multi-GPU path really performed: a one-rank RCCL group
+        # sends every block to itself (diagnostic: the whole N > 1 code path short of xGMI)
+        import torch.distributed as dist1
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     n_reads = args.reads
     bits_per_gpu = 1 << args.log2_bits

@@ -189,6 +189,9 @@ class ShardedBloomFilter:
         import os as _os
 
         self.force_exchange = bool(_os.environ.get("BTLBF_FORCE_EXCHANGE")) and dist.is_initialized()
+        # "2": as in production the rank's own block bypasses the collective (which then carries only
+        # zero-length messages in a one-rank group); "1": the own block goes through RCCL too
+        self.self_through_rccl = _os.environ.get("BTLBF_FORCE_EXCHANGE") == "1"
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         # gloo moves host memory: stage device tensors through the CPU (test mode only)
         self.stage_cpu = backend == "gloo"
@@ -296,12 +299,15 @@ class ShardedBloomFilter:
         return recv.to(dev) if recv.device != dev else recv
 
     def _sliced_all_to_all(self, recv, send, async_op):
-        """all-to-all of equal per-peer blocks, at most MSG_BYTES per message; returns the work handles"""
+        """all-to-all of equal per-peer blocks, at most MSG_BYTES per message; returns the work handles.
+        With RCCL the block a rank keeps for itself does not go through the collective at all: it is
+        one device-to-device copy on the compute stream (BTLBF_FORCE_EXCHANGE keeps it in, for tests)."""
         per = send.numel() // self.world
         step = max(1, self.MSG_BYTES // send.element_size())
-        if per <= step:
-            return [dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)]
         s2, r2 = send.view(self.world, per), recv.view(self.world, per)
+        local_self = not self.stage_cpu and not self.self_through_rccl
+        if per <= step and not local_self:
+            return [dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)]
         works = []
         for c0 in range(0, per, step):
             c1 = min(c0 + step, per)
@@ -310,9 +316,12 @@ class ShardedBloomFilter:
                 dist.all_to_all_single(tmp, s2[:, c0:c1].contiguous(), group=self.group)
                 r2[:, c0:c1] = tmp
             else:
-                works.append(dist.all_to_all([r2[p, c0:c1] for p in range(self.world)],
-                                             [s2[p, c0:c1] for p in range(self.world)], group=self.group,
-                                             async_op=async_op))
+                keep = (lambda p: p == self.rank) if local_self else (lambda p: False)
+                works.append(dist.all_to_all([r2[p, c0:c0] if keep(p) else r2[p, c0:c1] for p in range(self.world)],
+                                             [s2[p, c0:c0] if keep(p) else s2[p, c0:c1] for p in range(self.world)],
+                                             group=self.group, async_op=async_op))
+        if local_self:
+            r2[self.rank].copy_(s2[self.rank])
         return works
 
     def _all_gather_var(self, t, n):

@@ -205,11 +205,11 @@ def test_sharded_counting_filter_two_ranks_one_gpu(tmp_path):
         assert (n_reads // 2) * (L - k + 1) <= cnt[1] < cnt[0]
 
 
-def _nccl_one_rank_worker(rank, port, outdir):
+def _nccl_one_rank_worker(rank, port, outdir, mode):
     import btl_bloomfilter_amd as m
     from btl_bloomfilter_amd.sharded import ShardedBloomFilter
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BTLBF_FORCE_EXCHANGE="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BTLBF_FORCE_EXCHANGE=mode)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     bits, h, k, L, n = 1 << 33, 4, 31, 150, 1_500_000
@@ -232,9 +232,12 @@ def _nccl_one_rank_worker(rank, port, outdir):
 
 
 @pytest.mark.gpu
-def test_routed_path_over_rccl_with_one_rank(tmp_path):
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_routed_path_over_rccl_with_one_rank(tmp_path, mode):
     """the production exchange calls (torch.distributed on RCCL: grouped all-to-all of slices, async
     work handles, stream waits, the double-buffered schedule) with a one-rank group: every block
-    travels GPU -> RCCL -> same GPU.  Bodies and query results against the plain filter."""
-    mp.spawn(_nccl_one_rank_worker, args=(free_port(), str(tmp_path)), nprocs=1, join=True)
+    travels GPU -> RCCL -> same GPU (mode 1), or -- as in production -- the rank's own block is a local
+    copy and the collective carries the peers' blocks only, here none (mode 2).  Bodies and query results
+    against the plain filter."""
+    mp.spawn(_nccl_one_rank_worker, args=(free_port(), str(tmp_path), mode), nprocs=1, join=True)
     assert np.load(tmp_path / "nccl1.npy").all()
