@@ -11,8 +11,10 @@ One step = clear the filter, insert all reads (fused ntHash + atomicOr kernel), 
 value = (k-mers inserted + k-mers queried) / wall time, whole job.
 
 N > 1 (weak scaling): the filter is N x 64 GiB, hash-range sharded over the ranks
-(btl_bloomfilter_amd/sharded.py): every rank hashes its own 100 M reads, routes probe positions to
-the owning shard with an RCCL all-to-all, and (query) routes the answers back.
+(btl_bloomfilter_amd/sharded.py).  N = 2..4: the reads are all-gathered (1 byte per base over xGMI), every
+shard hashes all of them and applies the probes inside its own bit range; query partials are ANDed at
+the reads' owner.  N = 8: every rank hashes its own 100 M reads and routes 4-byte partitioned probe
+entries to the owning shard with RCCL all-to-alls; a query returns only the positions found clear.
 
 Large batches take the partitioned pipeline: pass A hash + radix partition of the
 probe positions, pass B split into 64 KiB segments, pass C OR / test in LDS.  Every kernel launch is
@@ -313,8 +315,11 @@ def main():
                                    "inserted then queried (all hits), reads resident in HBM"
                                    % (args.log2_bits, n_reads),
                        "filter_bits_total": bits_per_gpu * world, "kmers_per_pass": total_kmers,
-                       "parallelism": "1 GPU" if single else "hash-range shards x%d, partitioned routing, RCCL "
-                                      "all-to-all of 4-byte entries" % world},
+                       "parallelism": "1 GPU" if single else
+                                      ("hash-range shards x%d, reads all-gathered over RCCL, every shard hashes all "
+                                       "reads and keeps its window's probes" % world if flt.mode == "gather" else
+                                       "hash-range shards x%d, partitioned routing, RCCL all-to-all of 4-byte entries"
+                                       % world)},
             "insert_Mkmers_s": total_kmers / ins / 1e6, "query_Mkmers_s": total_kmers / qry / 1e6,
         }
         if single:

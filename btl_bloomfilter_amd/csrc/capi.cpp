@@ -918,8 +918,13 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 	int rc = seq_precheck(f, len);
 	if (rc)
 		return rc;
-	if (f->shard_count != 1)
-		return fail(BTLBF_EINVAL, "queries on a shard go through btlbf_positions_seqs/btlbf_test_positions");
+	// contains() on a bit-filter shard answers for the probes inside its window (ShardedBloomFilter's
+	// gather mode ANDs the shards' answers); the other query flavours need all h probes of a k-mer
+	if (f->shard_count != 1) {
+		if (op != OP_BF_CONTAINS)
+			return fail(BTLBF_EINVAL, "this query on a shard goes through btlbf_positions_seqs/btlbf_test_positions");
+		op = OP_BF_CONTAINS_WIN;
+	}
 	DeviceGuard g(f->device);
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	SeqView v;
@@ -941,7 +946,7 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 	a.counts = static_cast<uint64_t*>(ob_cnt.d);
 	a.min_out = static_cast<uint8_t*>(ob_min.d);
 	bool done = false;
-	if (op == OP_BF_CONTAINS || (op == OP_CBF_QUERY && !min_out)) { // minimum counts need the values: direct
+	if (op == OP_BF_CONTAINS || op == OP_BF_CONTAINS_WIN || (op == OP_CBF_QUERY && !min_out)) { // minimum counts need the values: direct
 		bool yes = false;
 		if ((rc = want_partitioned_query(f, a, s, &yes)))
 			return rc;
@@ -963,7 +968,7 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 		}
 	}
 	if (!done) {
-		ProfSpan ps(f, op == OP_BF_CONTAINS ? BTLBF_PROF_QUERY_DIRECT : BTLBF_PROF_OTHER, s);
+		ProfSpan ps(f, op == OP_BF_CONTAINS || op == OP_BF_CONTAINS_WIN ? BTLBF_PROF_QUERY_DIRECT : BTLBF_PROF_OTHER, s);
 		HIP_TRY(launch_seq_op(op, a, s));
 	}
 	if ((rc = ob_hit.finish(s)) || (rc = ob_valid.finish(s)) || (rc = ob_cnt.finish(s)) ||
@@ -1221,7 +1226,7 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 	// auto: one sweep of the local array (read + write) must be cheaper than the random atomics it
 	// replaces: ~ 2*bytes/5e12 s against probes/21e9 s, with a 2x margin; and the batch must be big
 	// enough to be worth five launches
-	const double probes = (double)len * f->hp.h;
+	const double probes = (double)len * f->hp.h * ((double)f->mod.shard_len / (double)f->mod.size);
 	return probes >= 0.02 * (double)f->local_bytes && probes >= 4.0e6;
 }
 
@@ -1255,7 +1260,8 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, Par
 	if (!plan_splits(pl, l0.regions) || !part_hash_fits(f->hp, l0.P))
 		return BTLBF_OK;
 	const uint64_t budget = scratch_budget(f);
-	const double ppt = probes_per_tile(f, base.layout);
+	// a shard fed every rank's reads (ShardedBloomFilter's gather mode) keeps only its window's share
+	const double ppt = probes_per_tile(f, base.layout) * ((double)f->mod.shard_len / (double)f->mod.size);
 	uint64_t tiles = *total_tiles;
 	for (int iter = 0; iter < 64; ++iter) {
 		plan_caps(pl, (double)tiles * ppt, 0);
@@ -1347,7 +1353,8 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	sd.fail_cap = kFailCap;
 	sd.counting = f->kind == BTLBF_COUNTING8;
 	sd.threshold = f->thr;
-	const int direct_op = sd.counting ? OP_CBF_QUERY : OP_BF_CONTAINS;
+	sd.pos_base = f->mod.shard_lo; // the fail set is keyed by global position
+	const int direct_op = sd.counting ? OP_CBF_QUERY : f->shard_count != 1 ? OP_BF_CONTAINS_WIN : OP_BF_CONTAINS;
 	uint64_t* table = sd.fail_list + kFailCap;
 	if (counts)
 		HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
@@ -1399,7 +1406,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* yes)
 {
 	*yes = false;
-	if (f->shard_count != 1 || f->query_mode == BTLBF_INSERT_DIRECT)
+	if (f->query_mode == BTLBF_INSERT_DIRECT || (f->shard_count != 1 && f->kind != BTLBF_BLOOM))
 		return BTLBF_OK;
 	if (!part_supported_h(f->hp.h) || base.len == 0)
 		return BTLBF_OK;
@@ -1407,7 +1414,8 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 		*yes = true;
 		return BTLBF_OK;
 	}
-	if ((double)base.len * f->hp.h < 0.02 * (double)f->local_bytes || (double)base.len * f->hp.h < 4.0e6)
+	const double live = (double)base.len * f->hp.h * ((double)f->mod.shard_len / (double)f->mod.size);
+	if (live < 0.02 * (double)f->local_bytes || live < 4.0e6)
 		return BTLBF_OK;
 	// sample 64 tiles spread over the buffer with the direct kernel
 	const uint64_t tiles = (base.len + seq_tile_windows() - 1) / seq_tile_windows();
@@ -1421,7 +1429,10 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 		a.valid_bits = nullptr;
 		a.counts = reinterpret_cast<uint64_t*>(f->d_scalar);
 		a.min_out = nullptr;
-		HIP_TRY(launch_seq_op(f->kind == BTLBF_COUNTING8 ? OP_CBF_QUERY : OP_BF_CONTAINS, a, s));
+		HIP_TRY(launch_seq_op(f->kind == BTLBF_COUNTING8 ? OP_CBF_QUERY
+		                      : f->shard_count != 1      ? OP_BF_CONTAINS_WIN
+		                                                 : OP_BF_CONTAINS,
+		                      a, s));
 	}
 	unsigned long long c[2] = {0, 0};
 	HIP_TRY(hipMemcpyAsync(c, f->d_scalar, 16, hipMemcpyDeviceToHost, s));
@@ -1431,7 +1442,7 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 	// expected failed probes in the whole call (at most h per missing k-mer) must stay well below
 	// what the fail list holds per batch
 	const double miss = (double)(c[0] - c[1]) / (double)c[0];
-	*yes = miss * (double)base.len * f->hp.h < 0.25 * (double)kFailCap;
+	*yes = miss * live < 0.25 * (double)kFailCap;
 	return BTLBF_OK;
 }
 

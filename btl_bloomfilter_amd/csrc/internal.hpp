@@ -84,7 +84,8 @@ enum SeqOp : int {
 	OP_CBF_QUERY = 5,    // contains + optional min counts
 	OP_HASH_ONLY = 6,    // dense hashes / valid / strand output
 	OP_POSITIONS = 7,    // bucket positions by owning shard (multi-GPU)
-	OP_BF_RESOLVE = 8    // partitioned query, second step: windows with a probe in the failed-position set miss
+	OP_BF_RESOLVE = 8,   // partitioned query, second step: windows with a probe in the failed-position set miss
+	OP_BF_CONTAINS_WIN = 9 // contains() on one shard of a larger filter: only the probes inside its window are tested
 };
 
 // operations on precomputed hash rows (aux_kernels.hip)

@@ -114,6 +114,17 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 					}
 					hit_mask |= all << w;
 				}
+			} else if (OP == OP_BF_CONTAINS_WIN) {
+				if (ok) {
+					const uint32_t* words = static_cast<const uint32_t*>(a.filter);
+					uint32_t all = 1;
+					for (uint32_t i = 0; i < h; ++i) {
+						const uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod) - a.mod.shard_lo;
+						if (p < a.mod.shard_len)
+							all &= (bf_word(words, p) >> (p & 31)) & 1u;
+					}
+					hit_mask |= all << w;
+				}
 			} else if (OP == OP_BF_RESOLVE) {
 				// partitioned query, second step: a.buckets is the failed-position hash set
 				// (key = position + 1, 0 = empty, linear probing), a.bucket_cap its index mask
@@ -237,7 +248,8 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 
 		// ---- results ----
 		const uint64_t ob = (g0 >> 3) + tid;
-		if (OP == OP_BF_CONTAINS || OP == OP_BF_INSERT_CHECK || OP == OP_CBF_QUERY || OP == OP_BF_RESOLVE) {
+		if (OP == OP_BF_CONTAINS || OP == OP_BF_INSERT_CHECK || OP == OP_CBF_QUERY || OP == OP_BF_RESOLVE ||
+		    OP == OP_BF_CONTAINS_WIN) {
 			if (a.hit_bits && ob < out_bytes)
 				a.hit_bits[ob] = (uint8_t)hit_mask;
 		}
@@ -322,6 +334,7 @@ hipError_t launch_seq_op(int op, const SeqArgs& a_in, hipStream_t s)
 	case OP_HASH_ONLY: return launch_one<OP_HASH_ONLY>(a, s, grid, dyn);
 	case OP_POSITIONS: return launch_one<OP_POSITIONS>(a, s, grid, dyn);
 	case OP_BF_RESOLVE: return launch_one<OP_BF_RESOLVE>(a, s, grid, dyn);
+	case OP_BF_CONTAINS_WIN: return launch_one<OP_BF_CONTAINS_WIN>(a, s, grid, dyn);
 	default: return hipErrorInvalidValue;
 	}
 }

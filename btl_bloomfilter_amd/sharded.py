@@ -99,6 +99,19 @@ class HipShardOps:
                                               self._sp()))
         return out.value
 
+    # ---- gather mode: the shard is handed every rank's reads and keeps the probes inside its window ----
+    def insert_seqs(self, reads, read_len):
+        lay = self._lay(read_len)
+        _lib.check(self.L.btlbf_insert_seqs(self.f, C.c_void_p(reads.data_ptr()), reads.numel(), C.byref(lay), 0,
+                                            _lib.ORDER_PARALLEL, _lib.DEVICE, self._sp()))
+
+    def contains_seqs(self, reads, read_len, hit_bits, valid_bits):
+        """hit bit p = window p is clean and every probe of it that falls into this shard is set"""
+        lay = self._lay(read_len)
+        _lib.check(self.L.btlbf_contains_seqs(self.f, C.c_void_p(reads.data_ptr()), reads.numel(), C.byref(lay),
+                                              C.c_void_p(hit_bits.data_ptr()), C.c_void_p(valid_bits.data_ptr()),
+                                              None, _lib.DEVICE, self._sp()))
+
     # ---- routing on the partitioned pipeline (btlbf_route_* / btlbf_apply_routed) ----
     def _lay(self, read_len):
         lay = _lib.Layout()
@@ -162,7 +175,7 @@ class ShardedBloomFilter:
     which live on different shards, and is not offered)."""
 
     def __init__(self, global_bits, hash_num, kmer_size, device=0, group=None, ops=None, batch_reads=2_000_000,
-                 slack=1.25, route=True, batch_bytes_cap=0, pipeline=None, counting=False, threshold=0):
+                 slack=1.25, route=True, batch_bytes_cap=0, pipeline=None, counting=False, threshold=0, mode=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -179,6 +192,20 @@ class ShardedBloomFilter:
         self.batch_reads = batch_reads
         self.slack = slack
         self.route_enabled = route         # use the partitioned routing path when the geometry allows
+        # "gather": every rank receives every rank's reads (1 byte per base over xGMI instead of 4 bytes
+        # per probe) and applies the probes inside its own window -- W times the hashing, no probe
+        # exchange; "exchange": the routed / direct paths below.  auto = gather for 2..4 ranks: xGMI is one
+        # link per GPU pair, so the probe exchange is link-bound at small W.
+        import os as _os0
+
+        mode = mode or _os0.environ.get("BTLBF_SHARD_MODE") or "auto"
+        if mode not in ("auto", "gather", "exchange"):
+            raise ValueError("mode must be auto, gather or exchange")
+        can_gather = not self.counting and hasattr(self.ops, "insert_seqs")
+        if mode == "gather" and not can_gather:
+            raise ValueError("gather mode: bit filters on the HIP ops only")
+        self.mode = "gather" if can_gather and (mode == "gather" or (mode == "auto" and 2 <= self.world <= 4)) \
+            else "exchange"
         self.batch_bytes_cap = batch_bytes_cap
         # routed path: keep the exchange of batch i in flight while batch i+1 is routed (two buffer
         # sets).  None = whenever the exchange is asynchronous (RCCL); True forces the same schedule
@@ -457,8 +484,102 @@ class ShardedBloomFilter:
                 counts[1] = ops.popcount_bits(hit_bits[: (reads.numel() + 63) // 64]) if reads.numel() else 0
         return True
 
+    # ---- gather mode ------------------------------------------------------------------------------
+    GATHER_BYTES = 16 << 30  # gathered reads per round, all ranks together
+
+    def _gather_start(self, out, piece):
+        """out[p] := rank p's piece, for every p.  RCCL: grouped sends/receives of at most MSG_BYTES,
+        asynchronous (returns the work handles); the own piece is a device copy."""
+        W = self.world
+        o2 = out.view(W, piece.numel())
+        if W == 1:
+            o2[0].copy_(piece)
+            return []
+        if self.stage_cpu:  # gloo (tests)
+            parts = [torch.empty(piece.numel(), dtype=piece.dtype) for _ in range(W)]
+            dist.all_gather(parts, piece.cpu(), group=self.group)
+            for p in range(W):
+                o2[p].copy_(parts[p])
+            return []
+        works = []
+        step = max(1, self.MSG_BYTES // piece.element_size())
+        for c0 in range(0, piece.numel(), step):
+            c1 = min(c0 + step, piece.numel())
+            works.append(dist.all_to_all([o2[p, c0:c0] if p == self.rank else o2[p, c0:c1] for p in range(W)],
+                                         [piece[c0:c0] if p == self.rank else piece[c0:c1] for p in range(W)],
+                                         group=self.group, async_op=True))
+        o2[self.rank].copy_(piece)
+        return works
+
+    def _gather_pass(self, reads, read_len, query, hit_bits=None, counts=None):
+        """One insert / query pass in gather mode.  Per round every rank contributes `chunk` bytes of reads
+        (padded with 'N': no k-mers); the gather of round i+1 is in flight while round i is hashed.  Query:
+        every shard answers "all of my probes of this window are set" for all W pieces, the partial bitmaps
+        go back to the pieces' owners (1 bit per window and peer) and are ANDed there."""
+        ops, W, dev = self.ops, self.world, self.ops.device
+        longest = self._max_over_ranks(reads.numel())
+        if longest == 0:
+            if counts is not None:
+                counts[0] = counts[1] = 0
+            return
+        unit = 64 * read_len
+        cap = self.batch_bytes_cap or max(self.GATHER_BYTES // W, unit)
+        rounds = max(-(-longest // cap), 2 if longest * W >= (1 << 30) else 1)
+        chunk = -(-(-(-longest // rounds)) // unit) * unit
+        rounds = -(-longest // chunk)
+        n_slots = 2 if rounds > 1 else 1
+        piece = [torch.empty(chunk, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
+        gathered = [torch.empty(W * chunk, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
+        words = chunk // 64
+        if query:
+            part = torch.empty(W * words, dtype=torch.int64, device=dev)
+            valid = torch.empty(W * words, dtype=torch.int64, device=dev)
+            back = torch.empty(W * words, dtype=torch.int64, device=dev)
+        n_valid = 0
+
+        def start(r):
+            slot = r % n_slots
+            mine = reads[r * chunk: (r + 1) * chunk]
+            piece[slot][: mine.numel()].copy_(mine)
+            piece[slot][mine.numel():].fill_(78)  # 'N'
+            return self._gather_start(gathered[slot], piece[slot])
+
+        works = start(0)
+        for r in range(rounds):
+            for w in works:
+                w.wait()
+            nxt = start(r + 1) if r + 1 < rounds else []
+            buf = gathered[r % n_slots]
+            if not query:
+                ops.insert_seqs(buf, read_len)
+            else:
+                ops.contains_seqs(buf, read_len, part, valid)
+                if W > 1:
+                    if self.stage_cpu:
+                        back.copy_(self._fixed_all_to_all(part))
+                    else:
+                        for w in self._sliced_all_to_all(back, part, async_op=True):
+                            w.wait()
+                    b2 = back.view(W, words)
+                    acc = b2[0].clone()
+                    for p in range(1, W):
+                        acc &= b2[p]
+                else:
+                    acc = part
+                have = min(max(reads.numel() - r * chunk, 0), chunk)
+                hw = (have + 63) // 64
+                hit_bits[r * words: r * words + hw].copy_(acc[:hw])
+                if counts is not None and hw:
+                    n_valid += ops.popcount_bits(valid.view(W, words)[self.rank, :hw])
+            works = nxt
+        if query and counts is not None:
+            counts[0] = n_valid
+            counts[1] = ops.popcount_bits(hit_bits[: (reads.numel() + 63) // 64]) if reads.numel() else 0
+
     def insert_reads(self, reads, read_len):
         """insertSeq over this rank's uniform-length reads (flat uint8 tensor)"""
+        if self.mode == "gather":
+            return self._gather_pass(reads, read_len, 0)
         if self._routed():
             if not self._routed_pass(reads, read_len, 0):
                 raise RuntimeError("routed insert: spill list overflow")
@@ -473,6 +594,9 @@ class ShardedBloomFilter:
     def contains_reads(self, reads, read_len, hit_bits, counts=None):
         """contains() of every window of this rank's reads -> hit_bits (int64 bitmap over the whole
         buffer, bit p = window at byte p); counts (optional int64[2]) = {clean windows, hits}"""
+        if self.mode == "gather":
+            self._gather_pass(reads, read_len, 1, hit_bits, counts)
+            return hit_bits
         if self._routed():
             if self._routed_pass(reads, read_len, 1, hit_bits, counts):
                 return hit_bits

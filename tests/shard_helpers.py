@@ -71,6 +71,29 @@ class OracleShardOps:
     def popcount_bits(self, bits):
         return int(np.unpackbits(bits.numpy().view(np.uint8)).sum())
 
+    # gather mode: all reads in, only the probes inside this shard's window count
+    def _own(self, buf, read_len):
+        lo = self.rank * self.shard_len
+        for r in range(buf.size // read_len):
+            pos, hv = self.o.nthash_seq(buf[r * read_len:(r + 1) * read_len].tobytes(), self.h, self.k)
+            for p, row in zip(pos, hv):
+                q = np.array([int(x) % self.bits for x in row], np.int64) - lo
+                yield r * read_len + int(p), q[(q >= 0) & (q < self.shard_len)]
+
+    def insert_seqs(self, reads, read_len):
+        for _, q in self._own(reads.numpy(), read_len):
+            np.bitwise_or.at(self.body, q >> 3, (1 << (q & 7)).astype(np.uint8))
+
+    def contains_seqs(self, reads, read_len, hit_bits, valid_bits):
+        n = reads.numel()
+        hit = np.zeros(n + (-n) % 64, np.uint8)
+        valid = np.zeros_like(hit)
+        for gp, q in self._own(reads.numpy(), read_len):
+            valid[gp] = 1
+            hit[gp] = bool((((self.body[q >> 3] >> (q & 7).astype(np.uint8)) & 1) == 1).all())
+        for dst, src in ((hit_bits, hit), (valid_bits, valid)):
+            dst[: hit.size // 64] = torch.from_numpy(np.packbits(src, bitorder="little").view(np.int64).copy())
+
     def local_body(self):
         return self.body.copy()
 
@@ -81,8 +104,9 @@ def _init(rank, world, port, backend="gloo"):
     dist.init_process_group(backend, rank=rank, world_size=world)
 
 
-def cpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
-    """gloo + oracle stand-in: validates bucketing / all-to-all / answer routing"""
+def cpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len, mode="exchange"):
+    """gloo + oracle stand-in: validates bucketing / all-to-all / answer routing (mode="gather": the
+    read gather, the window-partial answers and their AND at the reads' owner)"""
     from oracle.pyoracle import Oracle
 
     from btl_bloomfilter_amd.sharded import ShardedBloomFilter
@@ -90,7 +114,8 @@ def cpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
     _init(rank, world, port)
     o = Oracle()
     ops = OracleShardOps(bits, h, k, rank, world)
-    f = ShardedBloomFilter(bits, h, k, ops=ops, batch_reads=64)
+    f = ShardedBloomFilter(bits, h, k, ops=ops, batch_reads=64, mode=mode,
+                           batch_bytes_cap=(64 * read_len if mode == "gather" else 0))
     if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
         f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
     mine = torch.from_numpy(o.synth_reads(42, rank * n_reads, n_reads, read_len))
@@ -116,7 +141,7 @@ def gpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
 
     torch.cuda.set_device(0)
     _init(rank, world, port)
-    f = ShardedBloomFilter(bits, h, k, device=0, batch_reads=4096)
+    f = ShardedBloomFilter(bits, h, k, device=0, batch_reads=4096, mode="exchange")
     if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
         f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
     mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
@@ -136,8 +161,10 @@ def gpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
     dist.destroy_process_group()
 
 
-def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, route_bins=0, pipeline=None):
-    """the routed (partitioned) multi-GPU path with the real HIP kernels, all ranks on cuda:0"""
+def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, route_bins=0, pipeline=None,
+                      mode="exchange"):
+    """the routed (partitioned) multi-GPU path -- or, mode="gather", the gather path -- with the real HIP
+    kernels, all ranks on cuda:0"""
     if route_bins:
         os.environ["BTLBF_ROUTE_BINS"] = str(route_bins)
     import btl_bloomfilter_amd as m
@@ -146,10 +173,10 @@ def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, 
     torch.cuda.set_device(0)
     _init(rank, world, port)
     # several batches; pipeline=True runs the double-buffered schedule of the RCCL path over gloo
-    f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=4 << 20, pipeline=pipeline)
+    f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=4 << 20, pipeline=pipeline, mode=mode)
     if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
         f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
-    assert f._routed()
+    assert f.mode == mode and (mode == "gather" or f._routed())
     mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
     f.insert_reads(mine, read_len)
     torch.cuda.synchronize()
@@ -161,6 +188,10 @@ def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, 
     ref.setQueryMode("direct")
     ref.insertSeqs(m.synth_reads_device(42, 0, world * n_reads, read_len), read_len=read_len)
     res = {}
+    mine_body = f.ops.local_body()
+    whole = ref.download()
+    per = whole.size // world
+    res["body"] = (bool((whole[rank * per:(rank + 1) * per] == mine_body).all()), [0, 0], [0, 0])
     for name, q in (("hits", mine.clone()),
                     ("few_misses", mine.clone()),
                     ("many_misses", torch.cat([mine[: 3000 * read_len], m.synth_reads_device(43, rank * 50000, 50000, read_len)]))):

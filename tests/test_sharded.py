@@ -53,6 +53,19 @@ def test_sharded_routing_gloo_cpu(oracle, tmp_path, msg_bytes, monkeypatch):
     check_queries(oracle, body, bits, h, k, world, n_reads, L, str(tmp_path))
 
 
+@pytest.mark.parametrize("world,bits", [(2, 1 << 16), (3, 3 << 14)])
+def test_sharded_gather_mode_gloo_cpu(oracle, tmp_path, world, bits):
+    """gather mode over gloo with the oracle stand-in: several rounds of the read gather (the last one
+    padded), window-partial answers exchanged and ANDed at the reads' owner"""
+    h, k, n_reads, L = 4, 31, 100, 150
+    mp.spawn(cpu_worker, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L, "gather"), nprocs=world,
+             join=True)
+    body = expected(oracle, bits, h, k, world, n_reads, L)
+    got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+    assert (got == body).all(), "concatenated shard bodies differ from the single-filter body"
+    check_queries(oracle, body, bits, h, k, world, n_reads, L, str(tmp_path))
+
+
 def test_sharded_world1_matches_plain_filter_cpu(oracle):
     """world_size 1 without a process group: the same code path degenerates to a plain filter"""
     import torch
@@ -136,6 +149,31 @@ def test_sharded_routed_four_ranks_one_gpu(tmp_path):
         for name, (same, cnt, exp) in res.items():
             assert same, (rank, name)
             assert cnt == exp, (rank, name, cnt, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,bits", [(2, 1 << 30), (4, 1 << 30), (3, 3 << 28), (2, 5 * (1 << 27))])
+def test_sharded_gather_mode_one_gpu(tmp_path, world, bits):
+    """gather mode (the default for 2..4 ranks): reads are all-gathered, every shard hashes all of them and
+    keeps the probes inside its window (WINDOW pass A + local split/apply); query partials are ANDed at
+    the reads' owner.  Several rounds (4 MiB pieces), power-of-two and other geometries; shard bodies and
+    all-hit / few-miss / miss-heavy queries against one filter built by the direct kernels, and the
+    reference's golden digest where there is one."""
+    g = load_golden("digests.json")["bf_medium"]
+    h, k, L = g["h"], g["k"], g["read_len"]
+    n_reads = g["n_reads"] // world
+    mp.spawn(gpu_worker_routed, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L, 0, None, "gather"),
+             nprocs=world, join=True)
+    if bits == g["bits"] and n_reads * world == g["n_reads"]:
+        got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+        assert sha(got) == g["body_sha256"]
+    for rank in range(world):
+        res = eval(str(np.load(tmp_path / ("res%d.npy" % rank))[0]))
+        for name, (same, cnt, exp) in res.items():
+            assert same, (rank, name)
+            assert cnt == exp, (rank, name, cnt, exp)
+        assert res["hits"][1][0] == res["hits"][1][1] == n_reads * (L - k + 1)
+        assert res["few_misses"][1][1] < res["few_misses"][1][0]
 
 
 @pytest.mark.gpu
