@@ -918,12 +918,13 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 	int rc = seq_precheck(f, len);
 	if (rc)
 		return rc;
-	// contains() on a bit-filter shard answers for the probes inside its window (ShardedBloomFilter's
-	// gather mode ANDs the shards' answers); the other query flavours need all h probes of a k-mer
+	// contains() on a shard answers for the probes inside its window (ShardedBloomFilter's gather mode
+	// ANDs the shards' answers); the other query flavours need all h probes of a k-mer
 	if (f->shard_count != 1) {
-		if (op != OP_BF_CONTAINS)
+		if (op != OP_BF_CONTAINS && !(op == OP_CBF_QUERY && !min_out))
 			return fail(BTLBF_EINVAL, "this query on a shard goes through btlbf_positions_seqs/btlbf_test_positions");
-		op = OP_BF_CONTAINS_WIN;
+		if (op == OP_BF_CONTAINS)
+			op = OP_BF_CONTAINS_WIN;
 	}
 	DeviceGuard g(f->device);
 	hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1217,7 +1218,7 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 {
 	if (f->insert_mode == BTLBF_INSERT_DIRECT)
 		return false;
-	if (f->kind == BTLBF_COUNTING8 ? counting_op != BTLBF_INCREMENT_ALL || f->shard_count != 1 : f->kind != BTLBF_BLOOM)
+	if (f->kind == BTLBF_COUNTING8 ? counting_op != BTLBF_INCREMENT_ALL : f->kind != BTLBF_BLOOM)
 		return false;
 	if (!part_supported_h(f->hp.h) || len == 0)
 		return false;
@@ -1406,7 +1407,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* yes)
 {
 	*yes = false;
-	if (f->query_mode == BTLBF_INSERT_DIRECT || (f->shard_count != 1 && f->kind != BTLBF_BLOOM))
+	if (f->query_mode == BTLBF_INSERT_DIRECT)
 		return BTLBF_OK;
 	if (!part_supported_h(f->hp.h) || base.len == 0)
 		return BTLBF_OK;
@@ -1687,8 +1688,10 @@ extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
 			}
 		}
 	} else {
-		if (f->shard_count != 1)
-			return fail(BTLBF_EINVAL, "counting filters are not sharded in this version");
+		// a counting shard keeps the increments inside its window; the conservative update needs all h
+		// counters of a k-mer, which live on different shards
+		if (f->shard_count != 1 && (op != BTLBF_INCREMENT_ALL || order == BTLBF_ORDER_SERIAL))
+			return fail(BTLBF_EINVAL, "a counting-filter shard takes incrementAll in parallel order only");
 		if (op != BTLBF_INCREMENT_MIN && op != BTLBF_INCREMENT_ALL)
 			return fail(BTLBF_EINVAL, "op must be BTLBF_INCREMENT_MIN or BTLBF_INCREMENT_ALL");
 		kop = op == BTLBF_INCREMENT_MIN ? OP_CBF_INC_MIN : OP_CBF_INC_ALL;

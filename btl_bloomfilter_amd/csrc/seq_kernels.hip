@@ -149,9 +149,12 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 				const uint8_t* ctr = static_cast<const uint8_t*>(a.filter);
 				uint32_t mn = 0xff;
 				if (ok) {
-					for (uint32_t i = 0; i < h; ++i) {
-						const uint32_t v = ctr[reduce_mod<POW2>(wh.at(i), a.mod)];
-						mn = v < mn ? v : mn;
+					for (uint32_t i = 0; i < h; ++i) { // a shard sees the counters inside its window only
+						const uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod) - a.mod.shard_lo;
+						if (p < a.mod.shard_len) {
+							const uint32_t v = ctr[p];
+							mn = v < mn ? v : mn;
+						}
 					}
 					hit_mask |= (uint32_t)(mn >= a.threshold) << w;
 				}
@@ -160,8 +163,11 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 			} else if (OP == OP_CBF_INC_ALL) {
 				if (ok) {
 					uint32_t* words = static_cast<uint32_t*>(a.filter);
-					for (uint32_t i = 0; i < h; ++i)
-						cbf_inc_sat(words, reduce_mod<POW2>(wh.at(i), a.mod));
+					for (uint32_t i = 0; i < h; ++i) {
+						const uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod) - a.mod.shard_lo;
+						if (p < a.mod.shard_len)
+							cbf_inc_sat(words, p);
+					}
 				}
 			} else if (OP == OP_CBF_INC_MIN) {
 				if (ok) {

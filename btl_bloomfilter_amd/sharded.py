@@ -102,8 +102,8 @@ class HipShardOps:
     # ---- gather mode: the shard is handed every rank's reads and keeps the probes inside its window ----
     def insert_seqs(self, reads, read_len):
         lay = self._lay(read_len)
-        _lib.check(self.L.btlbf_insert_seqs(self.f, C.c_void_p(reads.data_ptr()), reads.numel(), C.byref(lay), 0,
-                                            _lib.ORDER_PARALLEL, _lib.DEVICE, self._sp()))
+        _lib.check(self.L.btlbf_insert_seqs(self.f, C.c_void_p(reads.data_ptr()), reads.numel(), C.byref(lay),
+                                            _lib.INCREMENT_ALL, _lib.ORDER_PARALLEL, _lib.DEVICE, self._sp()))
 
     def contains_seqs(self, reads, read_len, hit_bits, valid_bits):
         """hit bit p = window p is clean and every probe of it that falls into this shard is set"""
@@ -171,8 +171,8 @@ class HipShardOps:
 class ShardedBloomFilter:
     """counting=True: a sharded CountingBloomFilter<uint8_t> of `global_bits` counters -- insert_reads is
     incrementAll (exact, saturating; shard-local at the owners) and contains_reads is
-    "minimum >= threshold"; routed path only (the conservative update needs the h counters of a k-mer,
-    which live on different shards, and is not offered)."""
+    "minimum >= threshold"; gather mode or the routed path (the conservative update needs the h counters
+    of a k-mer, which live on different shards, and is not offered)."""
 
     def __init__(self, global_bits, hash_num, kmer_size, device=0, group=None, ops=None, batch_reads=2_000_000,
                  slack=1.25, route=True, batch_bytes_cap=0, pipeline=None, counting=False, threshold=0, mode=None):
@@ -187,8 +187,6 @@ class ShardedBloomFilter:
         self.counting = bool(counting)
         self.ops = ops if ops is not None else HipShardOps(global_bits, hash_num, kmer_size, self.rank, self.world,
                                                            device, counting=counting, threshold=threshold)
-        if self.counting and not (route and self.ops.route_supported(global_bits, self.world)):
-            raise ValueError("sharded counting filters need the routed path (power-of-two geometry, h <= 8)")
         self.batch_reads = batch_reads
         self.slack = slack
         self.route_enabled = route         # use the partitioned routing path when the geometry allows
@@ -201,11 +199,14 @@ class ShardedBloomFilter:
         mode = mode or _os0.environ.get("BTLBF_SHARD_MODE") or "auto"
         if mode not in ("auto", "gather", "exchange"):
             raise ValueError("mode must be auto, gather or exchange")
-        can_gather = not self.counting and hasattr(self.ops, "insert_seqs")
+        can_gather = hasattr(self.ops, "insert_seqs")
         if mode == "gather" and not can_gather:
-            raise ValueError("gather mode: bit filters on the HIP ops only")
+            raise ValueError("gather mode: these ops have no whole-buffer insert")
         self.mode = "gather" if can_gather and (mode == "gather" or (mode == "auto" and 2 <= self.world <= 4)) \
             else "exchange"
+        if self.counting and self.mode != "gather" and not (route and self.ops.route_supported(global_bits, self.world)):
+            raise ValueError("sharded counting filters need gather mode or the routed path (power-of-two "
+                             "geometry, h <= 8)")
         self.batch_bytes_cap = batch_bytes_cap
         # routed path: keep the exchange of batch i in flight while batch i+1 is routed (two buffer
         # sets).  None = whenever the exchange is asynchronous (RCCL); True forces the same schedule

@@ -78,8 +78,9 @@ int btlbf_create(btlbf_filter** out, int kind, uint64_t size, unsigned hash_num,
 /* One hash-range shard of a larger filter: positions are computed modulo
  * `global_size` and this object stores [shard_index*global_size/shard_count, +global_size/shard_count).
  * Concatenating the shard bodies in index order is the single-filter body.
- * btlbf_insert_seqs on a bit-filter shard sets the probes that fall inside its range and drops the
- * others; btlbf_contains_seqs answers "clean window and every probe inside my range is set".  So W
+ * btlbf_insert_seqs on a shard sets the probes that fall inside its range and drops the others
+ * (counting shards: BTLBF_INCREMENT_ALL in parallel order only); btlbf_contains_seqs answers "clean
+ * window and every probe inside my range is set" (counting: "... is at least the threshold").  So W
  * shards that are each handed the same reads build the single filter's body, and the AND of their
  * answers is the single filter's contains() ("gather mode" of btl_bloomfilter_amd/sharded.py: moves
  * reads instead of probes between GPUs).  Both take the partitioned pipeline like an unsharded filter. */

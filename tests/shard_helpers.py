@@ -222,15 +222,17 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def gpu_worker_counting(rank, world, port, outdir, counters, h, k, thr, n_reads, read_len):
-    """sharded CountingBloomFilter (incrementAll + contains) on the routed path, all ranks on cuda:0"""
+def gpu_worker_counting(rank, world, port, outdir, counters, h, k, thr, n_reads, read_len, mode="exchange"):
+    """sharded CountingBloomFilter (incrementAll + contains) on the routed path or in gather mode, all ranks
+    on cuda:0"""
     import btl_bloomfilter_amd as m
     from btl_bloomfilter_amd.sharded import ShardedBloomFilter
 
     torch.cuda.set_device(0)
     _init(rank, world, port)
     f = ShardedBloomFilter(counters, h, k, device=0, batch_bytes_cap=4 << 20, pipeline=True, counting=True,
-                           threshold=thr)
+                           threshold=thr, mode=mode)
+    assert f.mode == mode
     if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
         f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
     mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)

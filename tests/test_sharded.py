@@ -226,11 +226,13 @@ def test_bench_two_ranks_rehearsal(tmp_path):
 
 
 @pytest.mark.gpu
-def test_sharded_counting_filter_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("mode,world", [("exchange", 2), ("gather", 2), ("gather", 4)])
+def test_sharded_counting_filter_two_ranks_one_gpu(tmp_path, mode, world):
     """the counting filter shards like the bit filter -- incrementAll is shard-local at the
-    owners and exact (saturating), contains() = minimum >= threshold; against one unsharded filter"""
-    counters, h, k, thr, L, world, n_reads = 1 << 28, 3, 25, 2, 150, 2, 40000
-    mp.spawn(gpu_worker_counting, args=(world, free_port(), str(tmp_path), counters, h, k, thr, n_reads, L),
+    owners and exact (saturating), contains() = minimum >= threshold; against one unsharded filter.
+    Routed path and gather mode (counters inside the shard's window)."""
+    counters, h, k, thr, L, n_reads = 1 << 28, 3, 25, 2, 150, 80000 // world
+    mp.spawn(gpu_worker_counting, args=(world, free_port(), str(tmp_path), counters, h, k, thr, n_reads, L, mode),
              nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
     ref = np.load(tmp_path / "ref.npy")
