@@ -493,7 +493,7 @@ class ShardedBloomFilter:
         asynchronous (returns the work handles); the own piece is a device copy."""
         W = self.world
         o2 = out.view(W, piece.numel())
-        if W == 1:
+        if W == 1 and not self.force_exchange:
             o2[0].copy_(piece)
             return []
         if self.stage_cpu:  # gloo (tests)
@@ -506,10 +506,12 @@ class ShardedBloomFilter:
         step = max(1, self.MSG_BYTES // piece.element_size())
         for c0 in range(0, piece.numel(), step):
             c1 = min(c0 + step, piece.numel())
-            works.append(dist.all_to_all([o2[p, c0:c0] if p == self.rank else o2[p, c0:c1] for p in range(W)],
-                                         [piece[c0:c0] if p == self.rank else piece[c0:c1] for p in range(W)],
+            keep = (lambda p: p == self.rank and not self.self_through_rccl)  # noqa: E731
+            works.append(dist.all_to_all([o2[p, c0:c0] if keep(p) else o2[p, c0:c1] for p in range(W)],
+                                         [piece[c0:c0] if keep(p) else piece[c0:c1] for p in range(W)],
                                          group=self.group, async_op=True))
-        o2[self.rank].copy_(piece)
+        if not self.self_through_rccl:
+            o2[self.rank].copy_(piece)
         return works
 
     def _gather_pass(self, reads, read_len, query, hit_bits=None, counts=None):
@@ -555,7 +557,7 @@ class ShardedBloomFilter:
                 ops.insert_seqs(buf, read_len)
             else:
                 ops.contains_seqs(buf, read_len, part, valid)
-                if W > 1:
+                if W > 1 or self.force_exchange:
                     if self.stage_cpu:
                         back.copy_(self._fixed_all_to_all(part))
                     else:

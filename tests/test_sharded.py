@@ -245,7 +245,7 @@ def test_sharded_counting_filter_two_ranks_one_gpu(tmp_path, mode, world):
         assert (n_reads // 2) * (L - k + 1) <= cnt[1] < cnt[0]
 
 
-def _nccl_one_rank_worker(rank, port, outdir, mode):
+def _nccl_one_rank_worker(rank, port, outdir, mode, shard_mode="exchange"):
     import btl_bloomfilter_amd as m
     from btl_bloomfilter_amd.sharded import ShardedBloomFilter
 
@@ -253,8 +253,9 @@ def _nccl_one_rank_worker(rank, port, outdir, mode):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     bits, h, k, L, n = 1 << 33, 4, 31, 150, 1_500_000
-    f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=80 << 20)  # three batches, pipelined
-    f.MSG_BYTES = 64 << 20  # several slices per block
+    f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=80 << 20, mode=shard_mode)  # three batches, pipelined
+    assert f.mode == shard_mode
+    f.MSG_BYTES = (64 << 20) if shard_mode == "exchange" else (16 << 20)  # several slices per block
     reads = m.synth_reads_device(42, 0, n, L)
     f.insert_reads(reads, L)
     hit = torch.zeros((reads.numel() + 63) // 64, dtype=torch.int64, device="cuda")
@@ -280,4 +281,14 @@ def test_routed_path_over_rccl_with_one_rank(tmp_path, mode):
     copy and the collective carries the peers' blocks only, here none (mode 2).  Bodies and query results
     against the plain filter."""
     mp.spawn(_nccl_one_rank_worker, args=(free_port(), str(tmp_path), mode), nprocs=1, join=True)
+    assert np.load(tmp_path / "nccl1.npy").all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_gather_mode_over_rccl_with_one_rank(tmp_path, mode):
+    """gather mode's collective calls on RCCL with a one-rank group: the read gather in slices (async work
+    handles, two buffers, three rounds) and the exchange of the partial bitmaps; mode 1 sends the rank's
+    own piece through RCCL, mode 2 copies it locally as in production"""
+    mp.spawn(_nccl_one_rank_worker, args=(free_port(), str(tmp_path), mode, "gather"), nprocs=1, join=True)
     assert np.load(tmp_path / "nccl1.npy").all()
