@@ -486,94 +486,123 @@ class ShardedBloomFilter:
         return True
 
     # ---- gather mode ------------------------------------------------------------------------------
-    GATHER_BYTES = 16 << 30  # gathered reads per round, all ranks together
+    GATHER_BYTES = 48 << 30  # peers' reads held per round, all peers together
 
-    def _gather_start(self, out, piece):
-        """out[p] := rank p's piece, for every p.  RCCL: grouped sends/receives of at most MSG_BYTES,
-        asynchronous (returns the work handles); the own piece is a device copy."""
-        W = self.world
-        o2 = out.view(W, piece.numel())
-        if W == 1 and not self.force_exchange:
-            o2[0].copy_(piece)
+    def _gather_start(self, out, piece, peers):
+        """out[i] := the piece of rank peers[i].  RCCL: grouped sends/receives of at most MSG_BYTES,
+        asynchronous (returns the work handles).  A rank is its own peer only in the one-rank test modes
+        (BTLBF_FORCE_EXCHANGE): its piece then goes through RCCL ("1") or is a device copy ("2")."""
+        W, n = self.world, piece.numel()
+        if not peers:
             return []
+        o2 = out.view(len(peers), n)
+        idx = {p: i for i, p in enumerate(peers)}
         if self.stage_cpu:  # gloo (tests)
-            parts = [torch.empty(piece.numel(), dtype=piece.dtype) for _ in range(W)]
+            parts = [torch.empty(n, dtype=piece.dtype) for _ in range(W)]
             dist.all_gather(parts, piece.cpu(), group=self.group)
-            for p in range(W):
-                o2[p].copy_(parts[p])
+            for p in peers:
+                o2[idx[p]].copy_(parts[p])
             return []
         works = []
+        none = piece[0:0]
+        local = self.rank in idx and not self.self_through_rccl
+        wire = lambda p: p in idx and not (p == self.rank and local)  # noqa: E731  (p's piece arrives over RCCL)
         step = max(1, self.MSG_BYTES // piece.element_size())
-        for c0 in range(0, piece.numel(), step):
-            c1 = min(c0 + step, piece.numel())
-            keep = (lambda p: p == self.rank and not self.self_through_rccl)  # noqa: E731
-            works.append(dist.all_to_all([o2[p, c0:c0] if keep(p) else o2[p, c0:c1] for p in range(W)],
-                                         [piece[c0:c0] if keep(p) else piece[c0:c1] for p in range(W)],
+        for c0 in range(0, n, step):
+            c1 = min(c0 + step, n)
+            works.append(dist.all_to_all([o2[idx[p], c0:c1] if wire(p) else none for p in range(W)],
+                                         [piece[c0:c1] if (p != self.rank or wire(p)) else none for p in range(W)],
                                          group=self.group, async_op=True))
-        if not self.self_through_rccl:
-            o2[self.rank].copy_(piece)
+        if local:
+            o2[idx[self.rank]].copy_(piece)
         return works
 
     def _gather_pass(self, reads, read_len, query, hit_bits=None, counts=None):
-        """One insert / query pass in gather mode.  Per round every rank contributes `chunk` bytes of reads
-        (padded with 'N': no k-mers); the gather of round i+1 is in flight while round i is hashed.  Query:
-        every shard answers "all of my probes of this window are set" for all W pieces, the partial bitmaps
-        go back to the pieces' owners (1 bit per window and peer) and are ANDed there."""
-        ops, W, dev = self.ops, self.world, self.ops.device
+        """One insert / query pass in gather mode.  Per round every rank contributes `chunk` bytes of its
+        reads (the last one padded with 'N': no k-mers) to all peers and, while they travel, hashes its
+        OWN chunk; then the peers' chunks, while the next round's are in flight.  Query: every shard
+        answers "all of my probes of this window are set" for every chunk it sees, the partial bitmaps of
+        the peers' chunks go back to their owners (1 bit per window and peer) and are ANDed there."""
+        ops, W, dev, rank = self.ops, self.world, self.ops.device, self.rank
         longest = self._max_over_ranks(reads.numel())
+        if query and counts is not None:
+            counts[0] = counts[1] = 0
         if longest == 0:
-            if counts is not None:
-                counts[0] = counts[1] = 0
             return
+        # one-rank test modes: the rank is its own (only) peer, so that the collectives carry data
+        peers = list(range(W)) if self.force_exchange else [p for p in range(W) if p != rank]
+        own_first = not self.force_exchange
         unit = 64 * read_len
-        cap = self.batch_bytes_cap or max(self.GATHER_BYTES // W, unit)
-        rounds = max(-(-longest // cap), 2 if longest * W >= (1 << 30) else 1)
+        cap = self.batch_bytes_cap or max(self.GATHER_BYTES // max(len(peers), 1), unit)
+        rounds = -(-longest // cap)
         chunk = -(-(-(-longest // rounds)) // unit) * unit
         rounds = -(-longest // chunk)
         n_slots = 2 if rounds > 1 else 1
-        piece = [torch.empty(chunk, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
-        gathered = [torch.empty(W * chunk, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
         words = chunk // 64
+        gathered = [torch.empty(len(peers) * chunk, dtype=torch.uint8, device=dev) for _ in range(n_slots)] \
+            if peers else []
+        pad = None  # send buffer for a chunk shorter than `chunk` (a rank's last one)
         if query:
-            part = torch.empty(W * words, dtype=torch.int64, device=dev)
-            valid = torch.empty(W * words, dtype=torch.int64, device=dev)
-            back = torch.empty(W * words, dtype=torch.int64, device=dev)
+            own_part = torch.empty(words, dtype=torch.int64, device=dev)
+            own_valid = torch.empty(words, dtype=torch.int64, device=dev)
+            if peers:
+                part = torch.empty(len(peers) * words, dtype=torch.int64, device=dev)
+                valid = torch.empty(len(peers) * words, dtype=torch.int64, device=dev)
+                sendb = torch.zeros(W * words, dtype=torch.int64, device=dev)
+                back = torch.empty(W * words, dtype=torch.int64, device=dev)
         n_valid = 0
 
         def start(r):
-            slot = r % n_slots
+            nonlocal pad
+            if not peers:
+                return []
             mine = reads[r * chunk: (r + 1) * chunk]
-            piece[slot][: mine.numel()].copy_(mine)
-            piece[slot][mine.numel():].fill_(78)  # 'N'
-            return self._gather_start(gathered[slot], piece[slot])
+            if mine.numel() < chunk:
+                if pad is None:
+                    pad = torch.empty(chunk, dtype=torch.uint8, device=dev)
+                pad[: mine.numel()].copy_(mine)
+                pad[mine.numel():].fill_(78)  # 'N'
+                mine = pad
+            return self._gather_start(gathered[r % n_slots], mine, peers)
 
         works = start(0)
         for r in range(rounds):
+            mine = reads[r * chunk: (r + 1) * chunk]
+            have = mine.numel()
+            hw = (have + 63) // 64
+            if own_first and have:  # hashed while the peers' chunks of this round arrive
+                if not query:
+                    ops.insert_seqs(mine, read_len)
+                else:
+                    ops.contains_seqs(mine, read_len, own_part, own_valid)
             for w in works:
                 w.wait()
+            # the next round's send buffer may be `pad`: this round's sends have completed (waited above)
             nxt = start(r + 1) if r + 1 < rounds else []
-            buf = gathered[r % n_slots]
-            if not query:
-                ops.insert_seqs(buf, read_len)
-            else:
-                ops.contains_seqs(buf, read_len, part, valid)
-                if W > 1 or self.force_exchange:
-                    if self.stage_cpu:
-                        back.copy_(self._fixed_all_to_all(part))
-                    else:
-                        for w in self._sliced_all_to_all(back, part, async_op=True):
-                            w.wait()
-                    b2 = back.view(W, words)
-                    acc = b2[0].clone()
-                    for p in range(1, W):
-                        acc &= b2[p]
+            if peers:
+                buf = gathered[r % n_slots]
+                if not query:
+                    ops.insert_seqs(buf, read_len)
                 else:
-                    acc = part
-                have = min(max(reads.numel() - r * chunk, 0), chunk)
-                hw = (have + 63) // 64
-                hit_bits[r * words: r * words + hw].copy_(acc[:hw])
-                if counts is not None and hw:
-                    n_valid += ops.popcount_bits(valid.view(W, words)[self.rank, :hw])
+                    ops.contains_seqs(buf, read_len, part, valid)
+                    # row p of sendb = my answer for rank p's chunk; row p of back = rank p's answer for mine
+                    sendb.view(W, words)[peers] = part.view(len(peers), words)
+                    if self.stage_cpu:
+                        back.copy_(self._fixed_all_to_all(sendb))
+                    else:
+                        for w in self._sliced_all_to_all(back, sendb, async_op=True):
+                            w.wait()
+            if query and hw:
+                if own_first:
+                    acc, val = own_part[:hw].clone(), own_valid
+                else:
+                    acc, val = None, valid.view(len(peers), words)[peers.index(rank)]
+                for p in peers:
+                    row = back.view(W, words)[p, :hw]
+                    acc = row.clone() if acc is None else acc.bitwise_and_(row)
+                hit_bits[r * words: r * words + hw].copy_(acc)
+                if counts is not None:
+                    n_valid += ops.popcount_bits(val[:hw])
             works = nxt
         if query and counts is not None:
             counts[0] = n_valid

@@ -21,10 +21,16 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
         ops.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ops.insert_seqs(reads, L)
+        own, peers = reads[: N * L], reads[N * L:]  # the two calls of a round: own chunk, then the peers'
+        ops.insert_seqs(own, L)
+        if W > 1:
+            ops.insert_seqs(peers, L)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        ops.contains_seqs(reads, L, hit, valid)
+        ops.contains_seqs(own, L, hit, valid)
+        if W > 1:
+            w0 = N * L // 64
+            ops.contains_seqs(peers, L, hit[w0:], valid[w0:])
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         res.append((t1 - t0, t2 - t1))
