@@ -5,9 +5,16 @@ into `world` contiguous bit ranges; rank g holds bits [g*M/W, (g+1)*M/W) in its 
 positions are `hash % M` exactly as in the single-GPU filter (BloomFilter.hpp:190), so the shard
 bodies concatenated in rank order ARE the single-filter body (and the .bf file).
 
-Two data paths:
-  routed (default for power-of-two geometries, large batches): the global position space is cut into
-    1024 bins; each rank hashes its reads and radix-partitions the probe positions into those bins in
+Three data paths:
+  gather (default for 2..4 ranks; any geometry; bit and counting filters): reads move, probes do not.
+    Every rank sends its reads to all peers (1 byte per base), hashes its own chunk while they travel
+    and then the peers' chunks, and keeps the probes that fall into its own bit range (pass A's WINDOW
+    variant; passes B and C then see the shard's 1/W of the probes).  A query answers "every probe of
+    this window inside my range is set" per shard; the partial bitmaps go back to the reads' owners
+    and are ANDed.  W times the hashing for 1/8 (W = 2) to 1/12 (W = 4) of the traffic: xGMI is one link per GPU
+    pair, so the probe exchange below is link-bound at small W.
+  routed (8 ranks; power-of-two geometries, large batches): the global position space is cut into
+    512 bins; each rank hashes its reads and radix-partitions the probe positions into those bins in
     LDS (4-byte entries, 128-byte chunks); the block of bins a shard owns is contiguous, so ONE
     fixed-size all-to-all moves it; the owner splits the received bins down to 64 KiB segments and
     ORs / tests them in LDS.  A query sends nothing back but the few positions found clear
@@ -18,9 +25,9 @@ Two data paths:
     query  : all-to-all of positions out, owners test bits, all-to-all of one byte per probe back in
              the same order; the origin ANDs the h answers of each k-mer into the per-window bitmap.
 
-The exchange is the only collective on the data path and it is a real data dependency: the h probes
-of one k-mer land on different shards.  Work is cut into batches of reads so that bucket memory
-stays bounded; the split sizes of each all-to-all are the bucket fills.
+The exchange (of reads or of probes) is the only collective on the data path and it is a real data
+dependency: the h probes of one k-mer land on different shards.  Work is cut into batches of reads so
+that buffer memory stays bounded.
 
 `ops` abstracts the per-rank compute: HipShardOps (the C ABI / HIP kernels) in production; the
 tests substitute a CPU stand-in to exercise this routing logic under gloo with world_size 2."""
