@@ -1166,48 +1166,40 @@ double probes_per_tile(const btlbf_filter* f, const LayoutParams& lay)
 }
 
 // run the split levels lv[1..] over the level-0 data `in0`, then the apply / test pass
-int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, int query, hipStream_t s)
+// in0 holds level-0 bins [bin_offset, bin_offset + n_bins0) of the local array (bin i of in0 = absolute bin
+// bin_offset + i); the whole array by default
+int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, int query, hipStream_t s,
+               uint32_t bin_offset = 0, uint32_t n_bins0 = 0)
 {
 	const int exact = sd.counting && !query; // counter increments: every entry exactly once
 	const int prof_split = query ? BTLBF_PROF_QUERY_SPLIT : BTLBF_PROF_INSERT_SPLIT;
 	const int prof_apply = query ? BTLBF_PROF_QUERY_TEST : BTLBF_PROF_INSERT_APPLY;
-	if (pl.n_levels >= 2 && pl.group_bins) {
-		// group by group: split the group's level-0 bins all the way down, then apply its segments
-		for (uint32_t b0 = 0; b0 < pl.lv[0].bins; b0 += pl.group_bins) {
-			PartIn in = in0;
-			uint32_t first_in = b0, abs_first = b0, n_in = std::min(pl.group_bins, pl.lv[0].bins - b0);
-			uint32_t in_shift = pl.lv[0].shift;
-			for (int j = 1; j < pl.n_levels; ++j) {
-				ProfSpan ps(f, prof_split, s);
-				HIP_TRY(launch_part_split(f->d_data, in, first_in, abs_first, n_in, pl.lv[j].out(), pl.lv[j].shift,
-				                          in_shift, sd, query, exact, s));
-				in = pl.lv[j].in();
-				first_in = 0;
-				abs_first *= pl.lv[j].P;
-				n_in *= pl.lv[j].P;
-				in_shift = pl.lv[j].shift;
-			}
-			const uint64_t seg_first = abs_first;
-			if (seg_first >= pl.n_seg)
-				break;
-			const uint64_t n_seg = std::min<uint64_t>(n_in, pl.n_seg - seg_first);
-			ProfSpan ps(f, prof_apply, s);
-			HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.seg_shift, seg_first, n_seg, in, sd, query, s));
+	if (n_bins0 == 0)
+		n_bins0 = pl.lv[0].bins - bin_offset;
+	// group by group: split the group's level-0 bins all the way down, then apply its segments
+	// (plans without groups: one group of everything)
+	const uint32_t group = pl.n_levels >= 2 && pl.group_bins ? pl.group_bins : n_bins0;
+	for (uint32_t b0 = 0; b0 < n_bins0; b0 += group) {
+		PartIn in = in0;
+		uint32_t first_in = b0, abs_first = bin_offset + b0, n_in = std::min(group, n_bins0 - b0);
+		uint32_t in_shift = pl.lv[0].shift;
+		for (int j = 1; j < pl.n_levels; ++j) {
+			ProfSpan ps(f, prof_split, s);
+			HIP_TRY(launch_part_split(f->d_data, in, first_in, abs_first, n_in, pl.lv[j].out(), pl.lv[j].shift,
+			                          in_shift, sd, query, exact, s));
+			in = pl.lv[j].in();
+			first_in = 0;
+			abs_first *= pl.lv[j].P;
+			n_in *= pl.lv[j].P;
+			in_shift = pl.lv[j].shift;
 		}
-		return BTLBF_OK;
+		const uint64_t seg_first = abs_first;
+		if (seg_first >= pl.n_seg)
+			break;
+		const uint64_t n_seg = std::min<uint64_t>(n_in, pl.n_seg - seg_first);
+		ProfSpan ps(f, prof_apply, s);
+		HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.seg_shift, seg_first, n_seg, in, sd, query, s));
 	}
-	PartIn in = in0;
-	uint32_t bins_in = pl.lv[0].bins, in_shift = pl.lv[0].shift;
-	for (int j = 1; j < pl.n_levels; ++j) {
-		ProfSpan ps(f, prof_split, s);
-		HIP_TRY(launch_part_split(f->d_data, in, 0, 0, bins_in, pl.lv[j].out(), pl.lv[j].shift, in_shift, sd, query,
-		                          exact, s));
-		in = pl.lv[j].in();
-		bins_in = pl.lv[j].bins;
-		in_shift = pl.lv[j].shift;
-	}
-	ProfSpan ps(f, prof_apply, s);
-	HIP_TRY(launch_part_apply(f->d_data, f->local_bytes, pl.seg_shift, 0, pl.n_seg, in, sd, query, s));
 	return BTLBF_OK;
 }
 
@@ -1558,29 +1550,12 @@ extern "C" int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, 
 	return BTLBF_OK;
 }
 
-extern "C" int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
-                                  uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards, int query,
-                                  uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream)
+namespace {
+
+// the owner's plan for blocks routed with `rp`: split levels below the level-0 bins of this shard
+int owner_plan(btlbf_filter* f, const RoutePlan& rp, const LayoutParams& lay, uint64_t plan_len, unsigned n_blocks,
+               unsigned n_shards, PartPlan& pl)
 {
-	if (!f || !recv_ent || !recv_cnt || n_blocks == 0)
-		return fail(BTLBF_EINVAL, "null argument");
-	if (f->shard_count != n_shards)
-		return fail(BTLBF_EINVAL, "filter is shard %u of %u, not of %u", f->shard_index, f->shard_count, n_shards);
-	if (query && (!fail_list || !fail_count))
-		return fail(BTLBF_EINVAL, "query needs a fail list");
-	DeviceGuard g(f->device);
-	hipStream_t s = static_cast<hipStream_t>(stream);
-	LayoutParams lay{nullptr, 0, 0};
-	if (layout) {
-		lay.n_seqs = layout->n_seqs;
-		lay.read_len = layout->starts ? 0 : layout->read_len;
-		lay.starts = layout->starts;
-	}
-	RoutePlan rp;
-	int rc = route_plan(f, plan_len, lay, n_shards, rp);
-	if (rc)
-		return rc;
-	PartPlan pl;
 	if (!plan_segments(f->mod.shard_len, pl, f->kind == BTLBF_COUNTING8 ? 0 : 3))
 		return fail(BTLBF_EINVAL, "shard too large for the partitioned pipeline");
 	pl.lv[0].bins = rp.bins_per_shard;
@@ -1592,6 +1567,67 @@ extern "C" int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const v
 	const uint64_t tile_w = (uint64_t)part_tile_windows();
 	const double entries = (double)((plan_len + tile_w - 1) / tile_w) * probes_per_tile(f, lay) * n_blocks / n_shards;
 	plan_caps(pl, entries, 1);
+	return BTLBF_OK;
+}
+
+LayoutParams layout_params(const btlbf_layout* layout)
+{
+	LayoutParams lay{nullptr, 0, 0};
+	if (layout) {
+		lay.n_seqs = layout->n_seqs;
+		lay.read_len = layout->starts ? 0 : layout->read_len;
+		lay.starts = layout->starts;
+	}
+	return lay;
+}
+
+} // namespace
+
+extern "C" int btlbf_route_geometry(btlbf_filter* f, uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards,
+                                    unsigned n_blocks, uint32_t* out4)
+{
+	if (!f || !out4)
+		return fail(BTLBF_EINVAL, "null argument");
+	const LayoutParams lay = layout_params(layout);
+	RoutePlan rp;
+	int rc = route_plan(f, plan_len, lay, n_shards, rp);
+	if (rc)
+		return rc;
+	PartPlan pl;
+	if ((rc = owner_plan(f, rp, lay, plan_len, n_blocks ? n_blocks : n_shards, n_shards, pl)))
+		return rc;
+	out4[0] = rp.bins_per_shard;
+	out4[1] = rp.regions;
+	out4[2] = rp.cap;
+	out4[3] = pl.n_levels >= 2 && pl.group_bins ? pl.group_bins : rp.bins_per_shard;
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_apply_routed_bins(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
+                                       unsigned first_bin, unsigned n_bins, uint64_t plan_len,
+                                       const btlbf_layout* layout, unsigned n_shards, int query, uint64_t* fail_list,
+                                       uint64_t fail_cap, uint64_t* fail_count, void* stream)
+{
+	if (!f || !recv_ent || !recv_cnt || n_blocks == 0)
+		return fail(BTLBF_EINVAL, "null argument");
+	if (f->shard_count != n_shards)
+		return fail(BTLBF_EINVAL, "filter is shard %u of %u, not of %u", f->shard_index, f->shard_count, n_shards);
+	if (query && (!fail_list || !fail_count))
+		return fail(BTLBF_EINVAL, "query needs a fail list");
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const LayoutParams lay = layout_params(layout);
+	RoutePlan rp;
+	int rc = route_plan(f, plan_len, lay, n_shards, rp);
+	if (rc)
+		return rc;
+	PartPlan pl;
+	if ((rc = owner_plan(f, rp, lay, plan_len, n_blocks, n_shards, pl)))
+		return rc;
+	const uint32_t group = pl.n_levels >= 2 && pl.group_bins ? pl.group_bins : rp.bins_per_shard;
+	if (n_bins == 0 || first_bin + n_bins > rp.bins_per_shard || first_bin % group || (n_bins % group && first_bin + n_bins != rp.bins_per_shard))
+		return fail(BTLBF_EINVAL, "bins [%u, +%u) are not whole groups of %u of this shard's %u level-0 bins", first_bin,
+		            n_bins, group, rp.bins_per_shard);
 	bool ok = false;
 	if ((rc = ensure_scratch(f, pl.bytes_total, &ok)))
 		return rc;
@@ -1606,9 +1642,24 @@ extern "C" int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const v
 	sd.fail_cap = fail_cap;
 	sd.counting = f->kind == BTLBF_COUNTING8; // incrementAll / counter >= threshold at the owner
 	sd.threshold = f->thr;
-	PartIn in0{n_blocks, rp.bins_per_shard, rp.regions, rp.cap, static_cast<const uint32_t*>(recv_cnt),
+	PartIn in0{n_blocks, n_bins, rp.regions, rp.cap, static_cast<const uint32_t*>(recv_cnt),
 	           static_cast<const uint32_t*>(recv_ent)};
-	return run_levels(f, pl, in0, sd, query, s);
+	return run_levels(f, pl, in0, sd, query, s, first_bin, n_bins);
+}
+
+extern "C" int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
+                                  uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards, int query,
+                                  uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream)
+{
+	if (!f)
+		return fail(BTLBF_EINVAL, "null argument");
+	const LayoutParams lay = layout_params(layout);
+	RoutePlan rp;
+	int rc = route_plan(f, plan_len, lay, n_shards, rp);
+	if (rc)
+		return rc;
+	return btlbf_apply_routed_bins(f, recv_ent, recv_cnt, n_blocks, 0, rp.bins_per_shard, plan_len, layout, n_shards,
+	                               query, fail_list, fail_cap, fail_count, stream);
 }
 
 extern "C" int btlbf_apply_spill(btlbf_filter* f, const uint64_t* global_pos, uint64_t n, int query,

@@ -151,6 +151,22 @@ class HipShardOps:
                                              fail_list.numel() if fail_list is not None else 0, ptr(fail_count),
                                              self._sp()))
 
+    def route_geometry(self, plan_len, read_len):
+        """(level-0 bins per shard, regions per bin, 128-byte chunks per region, bins per group)"""
+        out = (C.c_uint32 * 4)()
+        lay = self._lay(read_len)
+        _lib.check(self.L.btlbf_route_geometry(self.f, plan_len, C.byref(lay), self.world, self.world, out))
+        return tuple(int(v) for v in out)
+
+    def apply_routed_bins(self, recv_ent, recv_cnt, n_blocks, first_bin, n_bins, plan_len, read_len, query, fail_list,
+                          fail_count):
+        lay = self._lay(read_len)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _lib.check(self.L.btlbf_apply_routed_bins(self.f, ptr(recv_ent), ptr(recv_cnt), n_blocks, first_bin, n_bins,
+                                                  plan_len, C.byref(lay), self.world, int(query), ptr(fail_list),
+                                                  fail_list.numel() if fail_list is not None else 0, ptr(fail_count),
+                                                  self._sp()))
+
     def apply_spill(self, pos, query, fail_list, fail_count):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         _lib.check(self.L.btlbf_apply_spill(self.f, ptr(pos), pos.numel(), int(query), ptr(fail_list),
@@ -334,22 +350,28 @@ class ShardedBloomFilter:
         return recv.to(dev) if recv.device != dev else recv
 
     def _sliced_all_to_all(self, recv, send, async_op):
-        """all-to-all of equal per-peer blocks, at most MSG_BYTES per message; returns the work handles.
-        With RCCL the block a rank keeps for itself does not go through the collective at all: it is
-        one device-to-device copy on the compute stream (BTLBF_FORCE_EXCHANGE keeps it in, for tests)."""
+        """all-to-all of equal per-peer blocks of two flat tensors; see _rows_all_to_all"""
         per = send.numel() // self.world
-        step = max(1, self.MSG_BYTES // send.element_size())
-        s2, r2 = send.view(self.world, per), recv.view(self.world, per)
+        return self._rows_all_to_all(recv.view(self.world, per), send.view(self.world, per), async_op)
+
+    def _rows_all_to_all(self, r2, s2, async_op):
+        """row p of s2 goes to rank p, row p of r2 comes from rank p (2-D tensors [world, per] whose rows
+        are contiguous; the rows of s2 may be slices of larger blocks).  At most MSG_BYTES per message;
+        returns the work handles.  With RCCL the row a rank keeps for itself does not go through the
+        collective at all: it is one device-to-device copy on the compute stream (BTLBF_FORCE_EXCHANGE=1
+        keeps it in, for tests)."""
+        per = s2.shape[1]
+        step = max(1, self.MSG_BYTES // s2.element_size())
         local_self = not self.stage_cpu and not self.self_through_rccl
-        if per <= step and not local_self:
-            return [dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)]
+        if per <= step and not local_self and not self.stage_cpu and s2.is_contiguous() and r2.is_contiguous():
+            return [dist.all_to_all_single(r2.view(-1), s2.view(-1), group=self.group, async_op=async_op)]
         works = []
         for c0 in range(0, per, step):
             c1 = min(c0 + step, per)
             if self.stage_cpu:  # gloo (tests): contiguous copies of the slice through the single-tensor form
-                tmp = torch.empty((self.world, c1 - c0), dtype=send.dtype)
-                dist.all_to_all_single(tmp, s2[:, c0:c1].contiguous(), group=self.group)
-                r2[:, c0:c1] = tmp
+                tmp = torch.empty((self.world, c1 - c0), dtype=s2.dtype)
+                dist.all_to_all_single(tmp, s2[:, c0:c1].contiguous().cpu(), group=self.group)
+                r2[:, c0:c1] = tmp.to(r2.device)
             else:
                 keep = (lambda p: p == self.rank) if local_self else (lambda p: False)
                 works.append(dist.all_to_all([r2[p, c0:c0] if keep(p) else r2[p, c0:c1] for p in range(self.world)],
@@ -377,9 +399,9 @@ class ShardedBloomFilter:
         dist.all_gather(outs, pad, group=self.group)
         return torch.cat([o[:c] for o, c in zip(outs, cnts)]).to(dev)
 
-    def _route_batch_bytes(self, reads, read_len, n_slots=1):
-        """bytes of read buffer per batch (same on every rank): the send and receive block sets (n_slots
-        of each) and two split levels must fit in free HBM"""
+    def _route_batch_bytes(self, reads, read_len, n_slots=1, recv_sets=0.0):
+        """bytes of read buffer per batch (same on every rank): n_slots send block sets, the receive
+        buffers (recv_sets block sets: two groups of a block set) and two split levels must fit in free HBM"""
         longest = self._max_over_ranks(reads.numel())
         if longest == 0:
             return 0, 0
@@ -391,86 +413,130 @@ class ShardedBloomFilter:
         else:
             free = 1 << 40
         free = -self._max_over_ranks(-free)  # the smallest over ranks: every rank must plan the same batch
-        # per read byte: h*(L-k+1)/L probes * 4 B per entry, ~1.1x capacity; block sets: send (+ receive
-        # when there are peers), n_slots of each, + the owner's split levels, which hold 1/8 of a batch
-        sets = n_slots * (2 if self.world > 1 or self.force_exchange else 1) + 0.4
+        # per read byte: h*(L-k+1)/L probes * 4 B per entry, ~1.1x capacity; block sets: send, receive
+        # (when there are peers) + the owner's split levels, which hold 1/8 of a batch
+        sets = n_slots + recv_sets + 0.4
         per_byte = self.h * max(read_len - self.k + 1, 1) / read_len * 4 * 1.1 * sets
-        batch = int(0.7 * free / per_byte) // (64 * read_len) * (64 * read_len)
-        batch = max(batch, 64 * read_len)
+        unit = 64 * read_len
+        batch = int(0.78 * free / per_byte) // unit * unit
+        batch = max(batch, unit)
         if self.batch_bytes_cap:
-            batch = min(batch, self.batch_bytes_cap // (64 * read_len) * (64 * read_len) or 64 * read_len)
-        batch = min(batch, -(-longest // (64 * read_len)) * (64 * read_len))
+            batch = min(batch, self.batch_bytes_cap // unit * unit or unit)
+        n_batches = -(-longest // batch)
+        batch = -(-(-(-longest // n_batches)) // unit) * unit  # equal batches: no more memory than needed
         return batch, -(-longest // batch)
-
-    def _exchange_start(self, send, recv):
-        """fixed-size all-to-all of a uint8 block set.  RCCL: asynchronous on the communicator's stream
-        (returns the work handle; the compute stream goes on with the next batch); gloo (test mode):
-        synchronous through host memory; one rank: recv is send."""
-        if self.world == 1 and not self.force_exchange:
-            return None
-        if self.stage_cpu:
-            recv.copy_(self._fixed_all_to_all(send))
-            return None
-        wide = send.numel() % (8 * self.world) == 0  # 8-byte elements keep per-peer counts below 2^31
-        a, b = (recv.view(torch.int64), send.view(torch.int64)) if wide else (recv, send)
-        return self._sliced_all_to_all(a, b, async_op=True)
 
     def _routed_pass(self, reads, read_len, query, hit_bits=None, counts=None):
         """One insert / query pass over this rank's reads on the routed path.  Per batch: route (pass A
-        with the global geometry) -> fixed-size all-to-all -> apply at the owners.  With RCCL the
-        exchange of batch i runs while batch i+1 is routed and batch i-1 applied (two buffer sets);
-        nothing in the loop waits on the host.  Spill and fail lists accumulate over the pass and are
-        dealt with once at its end."""
+        with the global geometry) into a send block set; the owner's bins then travel and are applied a
+        GROUP at a time (1/8 of a shard's level-0 bins: the unit the owner splits and applies anyway), so
+        the receive side needs two groups of buffer instead of two block sets and the exchange of group
+        g+1 overlaps the apply of group g.  With RCCL the next batch is routed on a second stream while
+        the groups of this one are exchanged and applied; nothing in the loop waits on the host.  Spill
+        and fail lists accumulate over the pass and are dealt with once at its end."""
         ops, W, dev = self.ops, self.world, self.ops.device
         exchanging = W > 1 or self.force_exchange
         pipelined = exchanging and (not self.stage_cpu if self.pipeline is None else bool(self.pipeline))
-        batch, n_batches = self._route_batch_bytes(reads, read_len, 2 if pipelined else 1)
+        n_slots = 2 if pipelined else 1
+        unit = 64 * read_len
+        bins, _, _, gb = ops.route_geometry(unit, read_len)  # bins per shard and per group: the same for any length
+        G = bins // gb if exchanging else 1
+        r_slots = 2 if G > 1 else 1
+        batch, n_batches = self._route_batch_bytes(reads, read_len, n_slots, r_slots / G if exchanging else 0.0)
         if n_batches == 0:
             return True
         ent_b, cnt_b = ops.route_plan(batch, read_len)
-        n_slots = 2 if pipelined else 1
+        ge, gc = ent_b // G, cnt_b // G  # bytes of one group inside one block
+        assert ge * G == ent_b and gc * G == cnt_b and ge % 8 == 0
         send_ent = [torch.empty(W * ent_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
         send_cnt = [torch.empty(W * cnt_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
         if exchanging:
-            recv_ent = [torch.empty_like(t) for t in send_ent]
-            recv_cnt = [torch.empty_like(t) for t in send_cnt]
-        else:
-            recv_ent, recv_cnt = send_ent, send_cnt
+            recv_ent = [torch.empty(W * ge, dtype=torch.uint8, device=dev) for _ in range(r_slots)]
+            recv_cnt = [torch.empty(W * gc, dtype=torch.uint8, device=dev) for _ in range(r_slots)]
         spill = torch.empty(self.SPILL_CAP, dtype=torch.int64, device=dev)
         spill_count = torch.zeros(1, dtype=torch.int64, device=dev)
         fail = torch.empty(self.FAIL_CAP, dtype=torch.int64, device=dev) if query else None
         fail_count = torch.zeros(1, dtype=torch.int64, device=dev) if query else None
         cnt2 = torch.zeros(2, dtype=torch.int64, device=dev) if query else None
+        # pipelined: routing runs on its own stream, the exchange + apply of the previous batch on the caller's
+        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        side = torch.cuda.Stream(dev) if (pipelined and cur is not None) else None
+        routed_ev, free_ev = [None] * n_slots, [None] * n_slots
+        if side is not None:
+            side.wait_stream(cur)
 
-        def finish(p):
-            slot, works = p
-            for ws in works:
-                for w in (ws or ()):
-                    if w is not None:
-                        w.wait()  # RCCL: the compute stream waits, the host does not
-            ops.apply_routed(recv_ent[slot], recv_cnt[slot], W, batch, read_len, query, fail, fail_count)
-
-        pending = None
-        for bi in range(n_batches):
+        def route(bi):
             slot = bi % n_slots
             off = bi * batch
             chunk = reads[off: off + batch]  # empty once this rank has run out of reads: it still takes part
             view = None
             if query:
-                w0, words = off // 64, (chunk.numel() + 63) // 64
-                view = hit_bits[w0: w0 + words]
-            ops.route(chunk, read_len, batch, query, send_ent[slot], send_cnt[slot], view, None, cnt2, spill,
-                      spill_count)
-            works = (self._exchange_start(send_ent[slot], recv_ent[slot]),
-                     self._exchange_start(send_cnt[slot], recv_cnt[slot]))
+                w0, nw = off // 64, (chunk.numel() + 63) // 64
+                view = hit_bits[w0: w0 + nw]
+            if side is None:
+                ops.route(chunk, read_len, batch, query, send_ent[slot], send_cnt[slot], view, None, cnt2, spill,
+                          spill_count)
+                return
+            if free_ev[slot] is not None:
+                side.wait_event(free_ev[slot])  # the exchanges that read this block set have completed
+            with torch.cuda.stream(side):
+                ops.route(chunk, read_len, batch, query, send_ent[slot], send_cnt[slot], view, None, cnt2, spill,
+                          spill_count)
+                routed_ev[slot] = torch.cuda.Event()
+                routed_ev[slot].record(side)
+
+        def group_rows(t, per_block, g, gbytes):
+            """rows [W, group bytes] of group g inside the W blocks of a send set, as 8-byte elements if possible"""
+            if gbytes % 8 == 0 and per_block % 8 == 0:
+                return t.view(torch.int64).view(W, per_block // 8)[:, g * gbytes // 8: (g + 1) * gbytes // 8]
+            return t.view(W, per_block)[:, g * gbytes: (g + 1) * gbytes]
+
+        def flat_rows(t, gbytes):
+            return t.view(torch.int64).view(W, gbytes // 8) if gbytes % 8 == 0 else t.view(W, gbytes)
+
+        def exchange(slot, g):
+            rs = g % r_slots
+            works = []
+            for snd, rcv, per_block, gbytes in ((send_ent[slot], recv_ent[rs], ent_b, ge),
+                                                (send_cnt[slot], recv_cnt[rs], cnt_b, gc)):
+                s2 = group_rows(snd, per_block, g, gbytes)
+                r2 = flat_rows(rcv, gbytes) if s2.dtype == torch.int64 else rcv.view(W, gbytes)
+                works += self._rows_all_to_all(r2, s2, async_op=not self.stage_cpu) or []
+            return [w for w in works if w is not None]
+
+        def finish(bi):
+            slot = bi % n_slots
+            if side is not None:
+                cur.wait_event(routed_ev[slot])
+            if not exchanging:
+                ops.apply_routed(send_ent[slot], send_cnt[slot], W, batch, read_len, query, fail, fail_count)
+                return
+            inflight = {g: exchange(slot, g) for g in range(min(r_slots, G))}
+            for g in range(G):
+                for w in inflight.pop(g):
+                    w.wait()  # RCCL: the compute stream waits, the host does not
+                rs = g % r_slots
+                ops.apply_routed_bins(recv_ent[rs], recv_cnt[rs], W, g * gb, gb, batch, read_len, query, fail,
+                                      fail_count)
+                if g + r_slots < G:
+                    inflight[g + r_slots] = exchange(slot, g + r_slots)  # into the buffer just applied
+            if side is not None:
+                free_ev[slot] = torch.cuda.Event()
+                free_ev[slot].record(cur)
+
+        pending = None
+        for bi in range(n_batches):
+            route(bi)
             if pipelined:
                 if pending is not None:
                     finish(pending)
-                pending = (slot, works)
+                pending = bi
             else:
-                finish((slot, works))
+                finish(bi)
         if pending is not None:
             finish(pending)
+        if side is not None:
+            cur.wait_stream(side)
         # entries that could not be staged at their origin travel as explicit positions (rare)
         n_spill = int(spill_count.item())
         if self._max_over_ranks(1 if n_spill > self.SPILL_CAP else 0):

@@ -257,6 +257,14 @@ int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, 
  *               split down to segments and ORed into (query == 0) or tested against (query != 0) this
  *               shard in LDS.  Positions found clear are appended to fail_list as GLOBAL positions
  *               (fail_count must be zeroed by the caller).
+ *  route_geometry / apply_routed_bins: the same, group by group.  out4 = {level-0 bins per shard B/n,
+ *               regions per bin, chunks (128 bytes) per region, bins per group}: a block is laid out
+ *               [bin][region][chunk], so the bins of one group are a contiguous slice of every block
+ *               (entries: bins*regions*chunks*128 bytes, counts: bins*regions*4 bytes).  An owner may
+ *               receive and apply its bins a group at a time -- recv_ent / recv_cnt then hold, per
+ *               origin block, only bins [first_bin, first_bin + n_bins) (whole groups) -- so that the
+ *               receive buffers are a fraction of a block set and the exchange of one group overlaps
+ *               the apply of the previous one.  n_blocks = 0 in route_geometry means n_shards.
  *  apply_spill : owner.  Insert / test explicit global positions (the gathered spill lists); positions
  *               of other shards are ignored.
  *  resolve_seqs: origin.  Clear the hit bit of every window that owns one of the (gathered) failed
@@ -270,6 +278,12 @@ int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf
 int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
                        uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards, int query,
                        uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream);
+int btlbf_route_geometry(btlbf_filter* f, uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards,
+                         unsigned n_blocks, uint32_t* out4);
+int btlbf_apply_routed_bins(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
+                            unsigned first_bin, unsigned n_bins, uint64_t plan_len, const btlbf_layout* layout,
+                            unsigned n_shards, int query, uint64_t* fail_list, uint64_t fail_cap,
+                            uint64_t* fail_count, void* stream);
 int btlbf_apply_spill(btlbf_filter* f, const uint64_t* global_pos, uint64_t n, int query, uint64_t* fail_list,
                       uint64_t fail_cap, uint64_t* fail_count, void* stream);
 int btlbf_resolve_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
