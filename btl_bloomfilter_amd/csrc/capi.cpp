@@ -1155,6 +1155,13 @@ unsigned cu_count(int device)
 	return (unsigned)cus;
 }
 
+// pass A gives every workgroup (= region) ceil(tiles / regions) tiles: capacities are planned for the
+// fullest region, which matters when a batch has only a few tiles per workgroup
+uint64_t tiles_for_caps(uint64_t tiles, uint32_t regions)
+{
+	return regions ? (tiles + regions - 1) / regions * regions : tiles;
+}
+
 double probes_per_tile(const btlbf_filter* f, const LayoutParams& lay)
 {
 	double frac = 1.0;
@@ -1257,7 +1264,7 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, Par
 	const double ppt = probes_per_tile(f, base.layout) * ((double)f->mod.shard_len / (double)f->mod.size);
 	uint64_t tiles = *total_tiles;
 	for (int iter = 0; iter < 64; ++iter) {
-		plan_caps(pl, (double)tiles * ppt, 0);
+		plan_caps(pl, (double)tiles_for_caps(tiles, l0.regions) * ppt, 0);
 		pl.bytes_total += extra_bytes;
 		if (pl.bytes_total <= budget || tiles <= 1)
 			break;
@@ -1478,7 +1485,7 @@ int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, uns
 	rp.bins_per_shard = rp.bins / n_shards;
 	rp.regions = cu_count(f->device);
 	const uint64_t tile_w = (uint64_t)part_tile_windows();
-	const double entries = (double)((len + tile_w - 1) / tile_w) * probes_per_tile(f, lay);
+	const double entries = (double)tiles_for_caps((len + tile_w - 1) / tile_w, rp.regions) * probes_per_tile(f, lay);
 	rp.cap = chunks_for(entries / ((double)rp.bins * rp.regions), 1);
 	rp.ent_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * rp.cap * (kChunk * 4);
 	rp.cnt_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * 4;
@@ -1565,7 +1572,8 @@ int owner_plan(btlbf_filter* f, const RoutePlan& rp, const LayoutParams& lay, ui
 		return fail(BTLBF_EINVAL, "unsupported shard geometry");
 	// every origin sends about entries/n_shards to this shard; n_blocks origins
 	const uint64_t tile_w = (uint64_t)part_tile_windows();
-	const double entries = (double)((plan_len + tile_w - 1) / tile_w) * probes_per_tile(f, lay) * n_blocks / n_shards;
+	const double entries =
+	    (double)tiles_for_caps((plan_len + tile_w - 1) / tile_w, rp.regions) * probes_per_tile(f, lay) * n_blocks / n_shards;
 	plan_caps(pl, entries, 1);
 	return BTLBF_OK;
 }
