@@ -292,3 +292,31 @@ def test_gather_mode_over_rccl_with_one_rank(tmp_path, mode):
     own piece through RCCL, mode 2 copies it locally as in production"""
     mp.spawn(_nccl_one_rank_worker, args=(free_port(), str(tmp_path), mode, "gather"), nprocs=1, join=True)
     assert np.load(tmp_path / "nccl1.npy").all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap", [1_000_000, 2_110_000, 2_500_000, 3_300_000])
+def test_routed_small_batches_with_uneven_tiles_per_workgroup(cap):
+    """batches of a few hundred pass-A tiles: 257 tiles over 256 workgroups means two tiles for half of
+    them and none for the rest -- region capacities must be planned for the fullest region (the first
+    version planned for the mean and overflowed into the spill list).  World 1, routed path, no exchange."""
+    import torch
+
+    import btl_bloomfilter_amd as m
+    from btl_bloomfilter_amd.sharded import ShardedBloomFilter
+
+    bits, h, k, L, n = 1 << 30, 4, 31, 150, 40000
+    f = ShardedBloomFilter(bits, h, k, device=0, batch_bytes_cap=cap, mode="exchange")
+    assert f._routed()
+    reads = m.synth_reads_device(42, 0, n, L)
+    f.insert_reads(reads, L)
+    ref = m.BloomFilter(bits, h, k)
+    ref.setInsertMode("direct")
+    ref.insertSeqs(reads, read_len=L)
+    assert (f.ops.local_body() == ref.download()).all()
+    q = torch.cat([reads[: 2000 * L], m.synth_reads_device(43, 0, 10, L)])
+    hit = torch.zeros((q.numel() + 63) // 64, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int64)
+    f.contains_reads(q, L, hit, cnt)
+    eh, _, ec = ref.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    assert bool((hit == eh).all().item()) and cnt.tolist() == ec.cpu().tolist()
