@@ -281,6 +281,46 @@ def test_spaced_seed_filter(bf, oracle):
     assert cnt.tolist() == [len(pos), len(pos)]
 
 
+def test_mibf_stage1_bit_vector(bf, oracle):
+    """stage 1 of the miBF build (MIBFConstructSupport.hpp:55-87 insertBVColli / insertBV,
+    MIBloomFilter.hpp:94-104) sets bit `hash % bv.size()` of an sdsl::bit_vector -- 64-bit words, LSB
+    first -- for the stHashIterator hashes of every k-mer and counts the k-mers whose h bits were all
+    set already.  On a little-endian machine that word array IS this engine's filter body, so the
+    spaced-seed BloomFilter is the drop-in for that stage: body == the word array, and the serial
+    insertAndCheck total == insertBVColli's return value."""
+    seeds = ["1110111011101110111011101110111", "1101101101101101011011011011011",
+             "1111001111001111111001111001111", "1011101011101011101011101011101"]
+    rng = np.random.RandomState(11)
+    base = rand_seq(rng, 6000, 0.003)
+    s = base + base[1000:3000] + rand_seq(rng, 3000, 0.0)  # a repeated stretch: collisions
+    k, h = 31, len(seeds)
+    size = 64 * 5003  # MIBloomFilter::calcOptimalSize returns a multiple of 64, not a power of two
+    pos, hv, _ = oracle.sthash_seq(s, seeds, 1, k)
+    words = np.zeros(size // 64, np.uint64)
+    colli = 0
+    for row in hv:  # the reference's loop, serial order
+        c = 0
+        for x in row:
+            p = int(x) % size
+            c += int(words[p >> 6] >> np.uint64(p & 63)) & 1
+            words[p >> 6] |= np.uint64(1 << (p & 63))
+        colli += c == h
+    assert colli > 0
+    # (a) whole-buffer insert, parallel order
+    flt = bf.BloomFilter(size, h, k)
+    flt.setSpacedSeeds(seeds, 1)
+    flt.insertSeqs(s)
+    assert (flt.download().view(np.uint64) == words).all()
+    # (b) insertBVColli: hash rows from the device iterator, applied in buffer order
+    rows, valid, _ = bf.sthash_seqs(s, seeds, 1, k)
+    vb = np.unpackbits(np.asarray(valid).view(np.uint8), bitorder="little")[: len(s)].astype(bool)
+    assert np.flatnonzero(vb).tolist() == pos.tolist()
+    f2 = bf.BloomFilter(size, h, k)
+    prev = f2.insertAndCheck(np.asarray(rows)[vb], serial=True)
+    assert int(np.asarray(prev).sum()) == colli
+    assert (f2.download().view(np.uint64) == words).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # counting filter
 # ---------------------------------------------------------------------------------------------
