@@ -116,7 +116,8 @@ class HipShardOps:
         """hit bit p = window p is clean and every probe of it that falls into this shard is set"""
         lay = self._lay(read_len)
         _lib.check(self.L.btlbf_contains_seqs(self.f, C.c_void_p(reads.data_ptr()), reads.numel(), C.byref(lay),
-                                              C.c_void_p(hit_bits.data_ptr()), C.c_void_p(valid_bits.data_ptr()),
+                                              C.c_void_p(hit_bits.data_ptr()),
+                                              C.c_void_p(valid_bits.data_ptr()) if valid_bits is not None else None,
                                               None, _lib.DEVICE, self._sp()))
 
     # ---- routing on the partitioned pipeline (btlbf_route_* / btlbf_apply_routed) ----
@@ -620,7 +621,8 @@ class ShardedBloomFilter:
             own_valid = torch.empty(words, dtype=torch.int64, device=dev)
             if peers:
                 part = torch.empty(len(peers) * words, dtype=torch.int64, device=dev)
-                valid = torch.empty(len(peers) * words, dtype=torch.int64, device=dev)
+                # the peers count their own clean windows; only the one-rank test modes need this rank's here
+                valid = None if own_first else torch.empty(len(peers) * words, dtype=torch.int64, device=dev)
                 sendb = torch.zeros(W * words, dtype=torch.int64, device=dev)
                 back = torch.empty(W * words, dtype=torch.int64, device=dev)
         n_valid = 0

@@ -92,6 +92,8 @@ class OracleShardOps:
             valid[gp] = 1
             hit[gp] = bool((((self.body[q >> 3] >> (q & 7).astype(np.uint8)) & 1) == 1).all())
         for dst, src in ((hit_bits, hit), (valid_bits, valid)):
+            if dst is None:
+                continue
             dst[: hit.size // 64] = torch.from_numpy(np.packbits(src, bitorder="little").view(np.int64).copy())
 
     def local_body(self):
