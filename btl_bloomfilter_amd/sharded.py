@@ -32,6 +32,7 @@ that buffer memory stays bounded.
 `ops` abstracts the per-rank compute: HipShardOps (the C ABI / HIP kernels) in production; the
 tests substitute a CPU stand-in to exercise this routing logic under gloo with world_size 2."""
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -218,9 +219,7 @@ class ShardedBloomFilter:
         # per probe) and applies the probes inside its own window -- W times the hashing, no probe
         # exchange; "exchange": the routed / direct paths below.  auto = gather for 2..4 ranks: xGMI is one
         # link per GPU pair, so the probe exchange is link-bound at small W.
-        import os as _os0
-
-        mode = mode or _os0.environ.get("BTLBF_SHARD_MODE") or "auto"
+        mode = mode or os.environ.get("BTLBF_SHARD_MODE") or "auto"
         if mode not in ("auto", "gather", "exchange"):
             raise ValueError("mode must be auto, gather or exchange")
         can_gather = hasattr(self.ops, "insert_seqs")
@@ -238,12 +237,10 @@ class ShardedBloomFilter:
         self.pipeline = pipeline
         # BTLBF_FORCE_EXCHANGE=1: run the routed path's exchange even with a single rank (a one-rank RCCL
         # group sends every block to itself) -- lets a one-GPU box exercise the real collective calls
-        import os as _os
-
-        self.force_exchange = bool(_os.environ.get("BTLBF_FORCE_EXCHANGE")) and dist.is_initialized()
+        self.force_exchange = bool(os.environ.get("BTLBF_FORCE_EXCHANGE")) and dist.is_initialized()
         # "2": as in production the rank's own block bypasses the collective (which then carries only
         # zero-length messages in a one-rank group); "1": the own block goes through RCCL too
-        self.self_through_rccl = _os.environ.get("BTLBF_FORCE_EXCHANGE") == "1"
+        self.self_through_rccl = os.environ.get("BTLBF_FORCE_EXCHANGE") == "1"
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         # gloo moves host memory: stage device tensors through the CPU (test mode only)
         self.stage_cpu = backend == "gloo"
