@@ -320,3 +320,52 @@ def test_routed_small_batches_with_uneven_tiles_per_workgroup(cap):
     f.contains_reads(q, L, hit, cnt)
     eh, _, ec = ref.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
     assert bool((hit == eh).all().item()) and cnt.tolist() == ec.cpu().tolist()
+
+
+@pytest.mark.gpu
+def test_apply_routed_bins_group_by_group_equals_whole_block():
+    """C ABI, owner side: the bins of a routed block applied a group at a time from compact per-group
+    buffers (btlbf_route_geometry / btlbf_apply_routed_bins) give the same filter as the whole block
+    (btlbf_apply_routed); bin ranges that are not whole groups are refused."""
+    import ctypes as C
+
+    import torch
+
+    import btl_bloomfilter_amd as m
+    from btl_bloomfilter_amd import _lib
+    from btl_bloomfilter_amd.sharded import HipShardOps
+
+    bits, h, k, L, n = 1 << 32, 4, 31, 150, 60000
+    reads = m.synth_reads_device(42, 0, n, L)
+    plan = reads.numel()
+    bodies = []
+    for grouped in (False, True):
+        ops = HipShardOps(bits, h, k, 0, 1, 0)
+        ent_b, cnt_b = ops.route_plan(plan, L)
+        bins, regions, cap, gb = ops.route_geometry(plan, L)
+        assert ent_b == bins * regions * cap * 128 and cnt_b == bins * regions * 4 and bins % gb == 0 and gb < bins
+        send_ent = torch.empty(ent_b, dtype=torch.uint8, device="cuda")
+        send_cnt = torch.empty(cnt_b, dtype=torch.uint8, device="cuda")
+        spill = torch.empty(1 << 16, dtype=torch.int64, device="cuda")
+        spill_count = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ops.route(reads, L, plan, 0, send_ent, send_cnt, None, None, None, spill, spill_count)
+        assert int(spill_count.item()) == 0
+        if not grouped:
+            ops.apply_routed(send_ent, send_cnt, 1, plan, L, 0, None, None)
+        else:
+            ge, gc = ent_b // (bins // gb), cnt_b // (bins // gb)
+            for g in reversed(range(bins // gb)):  # any order
+                e = send_ent[g * ge:(g + 1) * ge].clone()
+                c = send_cnt[g * gc:(g + 1) * gc].clone()
+                ops.apply_routed_bins(e, c, 1, g * gb, gb, plan, L, 0, None, None)
+            with pytest.raises(_lib.BtlbfError):  # half a group
+                ops.apply_routed_bins(send_ent, send_cnt, 1, 0, gb // 2 or gb + 1, plan, L, 0, None, None)
+            with pytest.raises(_lib.BtlbfError):  # beyond the shard's bins
+                ops.apply_routed_bins(send_ent, send_cnt, 1, bins, gb, plan, L, 0, None, None)
+        torch.cuda.synchronize()
+        bodies.append(ops.local_body())
+        ops.close()
+    ref = m.BloomFilter(bits, h, k)
+    ref.setInsertMode("direct")
+    ref.insertSeqs(reads, read_len=L)
+    assert (bodies[0] == ref.download()).all() and (bodies[1] == bodies[0]).all()
