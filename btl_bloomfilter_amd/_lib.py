@@ -74,6 +74,7 @@ _PROTOS = {
     "btlbf_get_profile": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint), C.c_int]),
     "btlbf_set_query_mode": (C.c_int, [_P, C.c_int]),
     "btlbf_set_spaced_seeds": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_uint, C.c_uint]),
+    "btlbf_compare": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
     "btlbf_insert_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_int, C.c_int, C.c_int, _P]),
     "btlbf_contains_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), _P, _P, _P, C.c_int, _P]),
     "btlbf_insert_and_check_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), _P, _P, _P, C.c_int, _P]),

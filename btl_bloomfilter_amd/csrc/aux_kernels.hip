@@ -202,6 +202,60 @@ hipError_t launch_popcount(const void* data, uint64_t nbytes, int mode, uint32_t
 	return hipGetLastError();
 }
 
+// ---- compare two arrays of the same geometry (btlbf_compare) ---------------------------------------
+// counting == 0: positions are bits; out[0] += bits that differ, out[1] += bits set only in a, out[2] += bits
+// set only in b.  counting != 0: positions are uint8_t counters; out[0] += counters that differ, out[1] +=
+// counters with a > b, out[2] += counters with a < b.
+__global__ __launch_bounds__(256) void compare_kernel(const uint2* a, const uint2* b, uint64_t n_vec, int counting,
+                                                      unsigned long long* out)
+{
+	unsigned long long gt = 0, lt = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec;
+	     i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint2 va = a[i], vb = b[i];
+		const uint32_t wa[2] = {va.x, va.y}, wb[2] = {vb.x, vb.y};
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			if (!counting) {
+				gt += __popc(wa[q] & ~wb[q]);
+				lt += __popc(wb[q] & ~wa[q]);
+			} else if (wa[q] != wb[q]) {
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const uint32_t ca = (wa[q] >> (8 * c)) & 0xff, cb = (wb[q] >> (8 * c)) & 0xff;
+					gt += ca > cb;
+					lt += ca < cb;
+				}
+			}
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		gt += __shfl_xor(gt, o, 64);
+		lt += __shfl_xor(lt, o, 64);
+	}
+	if ((threadIdx.x & 63) == 0 && (gt | lt)) {
+		atomicAdd(out, gt + lt);
+		atomicAdd(out + 1, gt);
+		atomicAdd(out + 2, lt);
+	}
+}
+
+hipError_t launch_compare(const void* a, const void* b, uint64_t nbytes, int counting, unsigned long long* out3,
+                          hipStream_t s)
+{
+	if (nbytes % 8)
+		return hipErrorInvalidValue;
+	const uint64_t n_vec = nbytes / 8;
+	if (n_vec == 0)
+		return hipSuccess;
+	uint64_t blocks = (n_vec + 255) / 256;
+	if (blocks > 4096)
+		blocks = 4096;
+	hipLaunchKernelGGL(compare_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint2*>(a),
+	                   static_cast<const uint2*>(b), n_vec, counting, out3);
+	return hipGetLastError();
+}
+
 // ---- synthetic reads --------------------------------------------------------------
 // read r, base j = "ACGT"[(w(r*wpr + j/32) >> 2*(j%32)) & 3], w(n) = mix64(seed + (n+1)*golden)
 __global__ __launch_bounds__(256) void synth_kernel(uint8_t* out, uint64_t seed, uint64_t first,

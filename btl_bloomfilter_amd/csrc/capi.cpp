@@ -697,6 +697,7 @@ extern "C" int btlbf_upload(btlbf_filter* f, const void* src, uint64_t offset, u
 	if (offset + nbytes > f->local_bytes)
 		return fail(BTLBF_EINVAL, "upload range exceeds the filter");
 	DeviceGuard g(f->device);
+	HIP_TRY(hipDeviceSynchronize());
 	HIP_TRY(hipMemcpy(static_cast<uint8_t*>(f->d_data) + offset, src, nbytes, hipMemcpyHostToDevice));
 	return BTLBF_OK;
 }
@@ -708,6 +709,7 @@ extern "C" int btlbf_download(const btlbf_filter* f, void* dst, uint64_t offset,
 	if (offset + nbytes > f->local_bytes)
 		return fail(BTLBF_EINVAL, "download range exceeds the filter");
 	DeviceGuard g(f->device);
+	HIP_TRY(hipDeviceSynchronize()); // DEVICE-mode calls may have run on non-blocking user streams
 	HIP_TRY(hipMemcpy(dst, static_cast<const uint8_t*>(f->d_data) + offset, nbytes, hipMemcpyDeviceToHost));
 	return BTLBF_OK;
 }
@@ -1162,14 +1164,10 @@ uint64_t tiles_for_caps(uint64_t tiles, uint32_t regions)
 	return regions ? (tiles + regions - 1) / regions * regions : tiles;
 }
 
-double probes_per_tile(const btlbf_filter* f, const LayoutParams& lay)
+// expected probes of one full pass-A tile (+1 so that capacities never come out as zero)
+double probes_per_tile(const btlbf_filter* f, const PartTiling& tl)
 {
-	double frac = 1.0;
-	if (!lay.starts && lay.read_len) {
-		const double L = lay.read_len;
-		frac = L >= f->hp.k ? (L - f->hp.k + 1) / L : 0.0;
-	}
-	return (double)part_tile_windows() * f->hp.h * frac + 1.0;
+	return tl.windows_per_tile * f->hp.h + 1.0;
 }
 
 // run the split levels lv[1..] over the level-0 data `in0`, then the apply / test pass
@@ -1232,12 +1230,10 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 
 // plan the single-GPU pipeline for a buffer and (re)allocate the scratch;
 // *ok = false means "not applicable, use the direct kernel"
-int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, PartPlan& pl, uint64_t* total_tiles,
+int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, PartPlan& pl, PartTiling* tiling,
                  uint8_t** extra, bool* ok)
 {
 	*ok = false;
-	const uint64_t tile_w = (uint64_t)part_tile_windows();
-	*total_tiles = (base.len + tile_w - 1) / tile_w;
 	if (!plan_segments(f->mod.shard_len, pl, f->kind == BTLBF_COUNTING8 ? 0 : 3))
 		return BTLBF_OK;
 	PartLevel& l0 = pl.lv[0];
@@ -1256,13 +1252,14 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, Par
 	}
 	l0.P = l0.bins;
 	l0.alloc_bins = l0.bins;
-	l0.regions = cu_count(f->device); // one pass-A workgroup per CU (LDS-bound)
+	l0.regions = part_hash_regions(f->hp, l0.P, cu_count(f->device)); // pass-A workgroups: one or two per CU
 	if (!plan_splits(pl, l0.regions) || !part_hash_fits(f->hp, l0.P))
 		return BTLBF_OK;
+	*tiling = part_tiling(f->hp, l0.P, base.layout, base.len);
 	const uint64_t budget = scratch_budget(f);
 	// a shard fed every rank's reads (ShardedBloomFilter's gather mode) keeps only its window's share
-	const double ppt = probes_per_tile(f, base.layout) * ((double)f->mod.shard_len / (double)f->mod.size);
-	uint64_t tiles = *total_tiles;
+	const double ppt = probes_per_tile(f, *tiling) * ((double)f->mod.shard_len / (double)f->mod.size);
+	uint64_t tiles = tiling->n_tiles;
 	for (int iter = 0; iter < 64; ++iter) {
 		plan_caps(pl, (double)tiles_for_caps(tiles, l0.regions) * ppt, 0);
 		pl.bytes_total += extra_bytes;
@@ -1286,12 +1283,13 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 {
 	*done = false;
 	PartPlan pl;
-	uint64_t total_tiles = 0;
+	PartTiling tiling;
 	uint8_t* extra = nullptr;
 	bool ok = false;
-	int rc = part_prepare(f, base, 0, pl, &total_tiles, &extra, &ok);
+	int rc = part_prepare(f, base, 0, pl, &tiling, &extra, &ok);
 	if (rc || !ok)
 		return rc;
+	const uint64_t total_tiles = tiling.n_tiles;
 	PartSide sd;
 	memset(&sd, 0, sizeof sd);
 	sd.counting = f->kind == BTLBF_COUNTING8;
@@ -1340,12 +1338,13 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 {
 	*done = false;
 	PartPlan pl;
-	uint64_t total_tiles = 0;
+	PartTiling tiling;
 	uint8_t* extra = nullptr;
 	bool ok = false;
-	int rc = part_prepare(f, base, kFailBytes, pl, &total_tiles, &extra, &ok);
+	int rc = part_prepare(f, base, kFailBytes, pl, &tiling, &extra, &ok);
 	if (rc || !ok)
 		return rc;
+	const uint64_t total_tiles = tiling.n_tiles;
 	PartSide sd;
 	memset(&sd, 0, sizeof sd);
 	sd.fail_count = reinterpret_cast<unsigned long long*>(extra);
@@ -1358,8 +1357,8 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	uint64_t* table = sd.fail_list + kFailCap;
 	if (counts)
 		HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
-	const uint64_t seq_tiles_all = (base.len + seq_tile_windows() - 1) / seq_tile_windows();
-	const uint64_t ratio = (uint64_t)part_tile_windows() / seq_tile_windows();
+	const uint64_t seq_tw = (uint64_t)seq_tile_windows();
+	const uint64_t seq_tiles_all = (base.len + seq_tw - 1) / seq_tw;
 	for (uint64_t t0 = 0; t0 < total_tiles; t0 += pl.tiles_per_batch) {
 		SeqArgs a = base;
 		a.first_tile = t0;
@@ -1379,9 +1378,12 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 		HIP_TRY(hipStreamSynchronize(s));
 		if (n_fail == 0)
 			continue;
-		// redo / refine this batch's window range with the direct kernels (their tiles are smaller)
-		const uint64_t first = t0 * ratio;
-		const uint64_t n = std::min<uint64_t>(a.n_tiles * ratio, seq_tiles_all - first);
+		// redo / refine this batch's window range with the direct kernels: their tiles that overlap the
+		// batch's bytes.  A tile more at either end is harmless: a failed position is a bit that IS clear,
+		// so clearing any window that owns it is right, and a direct redo computes the true answer
+		const uint64_t first = t0 * tiling.tile_bytes / seq_tw;
+		const uint64_t end_b = std::min<uint64_t>(base.len, (t0 + a.n_tiles) * (uint64_t)tiling.tile_bytes);
+		const uint64_t n = std::min<uint64_t>((end_b + seq_tw - 1) / seq_tw, seq_tiles_all) - first;
 		ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
 		if (n_fail > kFailCap) {
 			SeqArgs d = base;
@@ -1483,9 +1485,9 @@ int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, uns
 		return fail(BTLBF_EINVAL, "routing supports global filters of 2^29 .. 2^42 bits (2^26 .. 2^42 counters)");
 	rp.shift0 = lm - lb;
 	rp.bins_per_shard = rp.bins / n_shards;
-	rp.regions = cu_count(f->device);
-	const uint64_t tile_w = (uint64_t)part_tile_windows();
-	const double entries = (double)tiles_for_caps((len + tile_w - 1) / tile_w, rp.regions) * probes_per_tile(f, lay);
+	rp.regions = part_hash_regions(f->hp, rp.bins, cu_count(f->device));
+	const PartTiling tl = part_tiling(f->hp, rp.bins, lay, len);
+	const double entries = (double)tiles_for_caps(tl.n_tiles, rp.regions) * probes_per_tile(f, tl);
 	rp.cap = chunks_for(entries / ((double)rp.bins * rp.regions), 1);
 	rp.ent_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * rp.cap * (kChunk * 4);
 	rp.cnt_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * 4;
@@ -1537,9 +1539,8 @@ extern "C" int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, 
 	a.hit_bits = reinterpret_cast<uint8_t*>(hit_bits);
 	a.valid_bits = reinterpret_cast<uint8_t*>(valid_bits);
 	a.counts = counts;
-	const uint64_t tile_w = (uint64_t)part_tile_windows();
 	a.first_tile = 0;
-	a.n_tiles = (len + tile_w - 1) / tile_w;
+	a.n_tiles = part_tiling(f->hp, rp.bins, v.lay, len).n_tiles;
 	PartOut out{rp.bins, rp.regions, rp.cap, static_cast<uint32_t*>(send_cnt), static_cast<uint32_t*>(send_ent)};
 	PartSide sd;
 	memset(&sd, 0, sizeof sd);
@@ -1571,9 +1572,8 @@ int owner_plan(btlbf_filter* f, const RoutePlan& rp, const LayoutParams& lay, ui
 	if (pl.lv[0].shift < pl.seg_shift || !plan_splits(pl, pl.lv[0].regions))
 		return fail(BTLBF_EINVAL, "unsupported shard geometry");
 	// every origin sends about entries/n_shards to this shard; n_blocks origins
-	const uint64_t tile_w = (uint64_t)part_tile_windows();
-	const double entries =
-	    (double)tiles_for_caps((plan_len + tile_w - 1) / tile_w, rp.regions) * probes_per_tile(f, lay) * n_blocks / n_shards;
+	const PartTiling tl = part_tiling(f->hp, rp.bins, lay, plan_len);
+	const double entries = (double)tiles_for_caps(tl.n_tiles, rp.regions) * probes_per_tile(f, tl) * n_blocks / n_shards;
 	plan_caps(pl, entries, 1);
 	return BTLBF_OK;
 }
@@ -1972,6 +1972,7 @@ static int popcount_mode(btlbf_filter* f, int mode, uint64_t* out)
 	if (!f || !out)
 		return fail(BTLBF_EINVAL, "null argument");
 	DeviceGuard g(f->device);
+	HIP_TRY(hipDeviceSynchronize()); // DEVICE-mode calls may have run on non-blocking user streams
 	HIP_TRY(hipMemset(f->d_scalar, 0, 8));
 	HIP_TRY(launch_popcount(f->d_data, f->alloc_bytes, mode, f->thr, f->d_scalar, nullptr));
 	unsigned long long v = 0;
@@ -1992,6 +1993,28 @@ extern "C" int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out)
 	if (f && f->kind != BTLBF_COUNTING8)
 		return fail(BTLBF_EINVAL, "filtered_popcount needs a counting filter");
 	return popcount_mode(f, 2, out);
+}
+
+extern "C" int btlbf_compare(btlbf_filter* a, btlbf_filter* b, uint64_t* out3)
+{
+	if (!a || !b || !out3)
+		return fail(BTLBF_EINVAL, "null argument");
+	if (a->kind != b->kind || a->size != b->size || a->local_bytes != b->local_bytes ||
+	    a->mod.shard_lo != b->mod.shard_lo || a->device != b->device)
+		return fail(BTLBF_EINVAL, "btlbf_compare: the two filters differ in kind, size, shard range or device");
+	DeviceGuard g(a->device);
+	HIP_TRY(hipDeviceSynchronize()); // whatever streams the two filters were last used on
+	DevBuf acc;
+	HIP_TRY(acc.alloc(24));
+	HIP_TRY(hipMemset(acc.p, 0, 24));
+	HIP_TRY(launch_compare(a->d_data, b->d_data, a->alloc_bytes, a->kind == BTLBF_COUNTING8,
+	                       acc.as<unsigned long long>(), nullptr));
+	unsigned long long v[3] = {0, 0, 0};
+	HIP_TRY(hipMemcpy(v, acc.p, 24, hipMemcpyDeviceToHost));
+	out3[0] = v[0];
+	out3[1] = v[1];
+	out3[2] = v[2];
+	return BTLBF_OK;
 }
 
 // -------------------------------------------------------------------------------------------------

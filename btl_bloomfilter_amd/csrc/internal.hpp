@@ -127,6 +127,14 @@ struct SeqArgs {
 	uint64_t tiles_per_block;
 };
 
+// How pass A cuts a buffer into tiles (partition_kernels.hip: part_tiling).  All host-side planning is in
+// these tiles.
+struct PartTiling {
+	uint32_t tile_bytes;      // window starts per tile = bytes from one tile's start to the next
+	uint64_t n_tiles;         // tiles covering the buffer
+	double windows_per_tile;  // expected clean windows per full tile
+};
+
 // ---- partitioned insert / contains (partition_kernels.hip) -------------------------------------------
 // A SEGMENT is 2^seg_shift bits of the local array (64 KiB or 128 KiB: what one workgroup holds in
 // LDS).  A partition pass writes BINS; every bin is written by several workgroups, each into its own
@@ -163,10 +171,10 @@ struct PartSide {
 };
 
 // launchers (defined in the .hip files)
-int part_tile_windows();
+PartTiling part_tiling(const HashParams& hp, uint32_t p0, const LayoutParams& lay, uint64_t len);
 bool part_supported_h(uint32_t h);
-uint32_t part_hash_lds_bytes(const HashParams& hp, uint32_t p0);
 bool part_hash_fits(const HashParams& hp, uint32_t p0);
+uint32_t part_hash_regions(const HashParams& hp, uint32_t p0, uint32_t cus); // pass A workgroups = regions per bin
 hipError_t launch_part_hash(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd, int query,
                             hipStream_t s);
 // exact != 0: every entry counts (counter increments), so readers honour the exact entry count of a
@@ -187,6 +195,8 @@ hipError_t launch_serial_seq_update(const SeqArgs& a, int op, const uint64_t* ha
                                     const uint8_t* valid_bits, uint8_t* out, hipStream_t s);
 hipError_t launch_popcount(const void* data, uint64_t nbytes, int mode, uint32_t threshold,
                            unsigned long long* out, hipStream_t s);
+hipError_t launch_compare(const void* a, const void* b, uint64_t nbytes, int counting, unsigned long long* out3,
+                          hipStream_t s);
 hipError_t launch_synth(uint8_t* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t read_len,
                         hipStream_t s);
 hipError_t launch_microbench(void* data, uint64_t nbytes, int kind, uint64_t n_access,

@@ -15,20 +15,33 @@ namespace btlbf {
 // routing mode, where a.mod describes the GLOBAL filter).
 // WINDOW: the filter object is one shard of a larger filter and keeps only the positions inside its
 // window (a.mod.shard_lo, shard_len); otherwise every probe of a clean window is an entry.
-template <int H, bool POW2, bool SPACED, bool QUERY, bool WINDOW>
-__global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a, const PartOut out,
-                                                                const uint32_t bin_shift, const PartSide sd)
+// SMALL: the two-workgroups-per-CU geometry (partition_core.hpp): 512 threads, tiles of 4096 windows, 64 KiB
+// of rings; otherwise 1024 threads, tiles of 8192 windows, 128 KiB of rings.  a.first_tile / a.n_tiles /
+// a.tiles_per_block are in units of THIS kernel's tile.
+template <int H, bool POW2, bool SPACED, bool QUERY, bool WINDOW, bool SMALL>
+__global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1) void part_hash_kernel(
+    const SeqArgs a, const PartOut out, const uint32_t bin_shift, const PartSide sd)
 {
+	constexpr int NT = SMALL ? kPartThreadsS : kPartThreads;
+	constexpr int kTile = NT * kPartW;
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	__shared__ SeqShared sh;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t k = a.hp.k;
-	const uint32_t tile_cap = seq_tile_cap(kPartTile, k);
+	const uint32_t tile_cap = seq_tile_cap(kTile, k);
 	uint8_t* tile = dyn;
 	uint8_t* spaced_lds = dyn + tile_cap;
-	const PartLds pl = part_carve(dyn + tile_cap + seq_spaced_bytes(a.hp), out.P);
-	seq_setup_tables<kPartThreads, SPACED>(sh, a.hp, spaced_lds);
-	part_init<kPartThreads>(pl, out.P);
+	uint8_t* part_base = dyn + tile_cap + seq_spaced_bytes(a.hp);
+	PartLds pl{};
+	PartLdsS ps{};
+	if (SMALL) {
+		ps = part_carve_s(part_base, out.P);
+		part_init_s(ps, out.P);
+	} else {
+		pl = part_carve(part_base, out.P);
+		part_init<kPartThreads>(pl, out.P);
+	}
+	seq_setup_tables<NT, SPACED>(sh, a.hp, spaced_lds);
 
 	uint32_t* words = static_cast<uint32_t*>(a.filter);
 	const uint32_t ent_mask = bin_shift >= 32 ? 0xffffffffu : (1u << bin_shift) - 1;
@@ -43,29 +56,36 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 	const uint32_t L = a.layout.starts ? 0 : a.layout.read_len;
 	uint32_t tile_off = 0;
 	if (L && t_begin < t_end)
-		tile_off = (uint32_t)((t_begin * (uint64_t)kPartTile) % L);
-	const uint32_t tile_step = L ? (uint32_t)(kPartTile % L) : 0;
+		tile_off = (uint32_t)((t_begin * (uint64_t)kTile) % L);
+	const uint32_t tile_step = L ? (uint32_t)(kTile % L) : 0;
 
 	__syncthreads(); // tables and partition state ready
 	STAMP_DECL;
 	StageRaw<kPartW> raw;
 	if (t_begin < t_end)
-		seq_stage_load<kPartThreads, kPartW>(raw, a.seq, a.len, k, t_begin * (uint64_t)kPartTile);
+		seq_stage_load<NT, kPartW>(raw, a.seq, a.len, k, t_begin * (uint64_t)kTile);
+	if (SMALL) {
+		// the first tile's words land here; every later tile's land inside the partition rounds (below), so
+		// the top of the loop never waits on vector memory -- a wait there would sit behind the flush stores
+#pragma unroll
+		for (int q = 0; q < kPartW / 4 + 1; ++q)
+			asm volatile("" : "+v"(raw.w[q]));
+	}
 	for (uint64_t t = t_begin; t < t_end; ++t) {
-		const uint64_t g0 = t * (uint64_t)kPartTile;
+		const uint64_t g0 = t * (uint64_t)kTile;
 		STAMP(0);
 		// this tile's words were requested a whole tile ago; the next tile's are requested now and stay
 		// in flight while this one is hashed and partitioned
 #ifdef BTLBF_PHASE_STAMPS
-		const uint32_t mis = seq_stage_convert<kPartThreads, kPartW, false, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+		const uint32_t mis = seq_stage_convert<NT, kPartW, false, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
 		STAMP(1); // conversion of this thread's words
 		__syncthreads();
 		STAMP(3); // waiting for the other waves
 #else
-		const uint32_t mis = seq_stage_convert<kPartThreads, kPartW, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+		const uint32_t mis = seq_stage_convert<NT, kPartW, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
 #endif
 		if (t + 1 < t_end)
-			seq_stage_load<kPartThreads, kPartW>(raw, a.seq, a.len, k, g0 + kPartTile);
+			seq_stage_load<NT, kPartW>(raw, a.seq, a.len, k, g0 + kTile);
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
 
 		// the lane hashes its 8 consecutive windows with ONE start-up; after every 4 windows the
@@ -73,7 +93,22 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 		// registers across it)
 		uint32_t bin[kPartHalf * H], val[kPartHalf * H];
 		uint32_t vmask = 0, live = 0;
+#ifdef BTLBF_EXP_NOHASH
+		// diagnostic build: no hashing -- pseudo-random entries from the window index (timing of the partition alone)
+		auto fake_windows = [&](auto&& f) {
+#pragma unroll
+			for (int w = 0; w < kPartW; ++w) {
+				WinHash<SPACED> wh;
+				wh.kms = 0;
+				wh.stn = 0;
+				wh.bcan = (uint64_t)((uint32_t)(g0 + tid * kPartW + w) * 2654435761u) << 13;
+				f(w, true, wh);
+			}
+		};
+		fake_windows([&](int w, bool ok, const WinHash<SPACED>& wh) {
+#else
 		seq_lane_windows<SPACED, kPartW, H>(tile, sh, a.hp, spaced_lds, tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
+#endif
 			vmask |= (uint32_t)ok << w;
 			const int w4 = w % kPartHalf;
 			if (w4 == 0)
@@ -82,7 +117,11 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 				live |= (uint32_t)ok << w4;
 #pragma unroll
 			for (int i = 0; i < H; ++i) {
+#ifdef BTLBF_EXP_NOHASH
+				uint64_t p = (wh.bcan + (uint64_t)i * 0x9E3779B97F4A7C15ULL) & a.mod.mask;
+#else
 				uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
+#endif
 				if (WINDOW) {
 					p -= a.mod.shard_lo;
 					live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
@@ -90,9 +129,31 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 				bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
 				val[w4 * H + i] = (uint32_t)p & ent_mask;
 			}
+#ifdef BTLBF_EXP_NOPART
+			// diagnostic build: no partition -- the entries are folded into a value that is (never) stored
 			if (w4 == kPartHalf - 1) {
+#pragma unroll
+				for (int e = 0; e < kPartHalf * H; ++e)
+					my_valid += (bin[e] ^ val[e]) == 0x12345u;
+			}
+			if (false) {
+#else
+			if (w4 == kPartHalf - 1) {
+#endif
 				STAMP(2);
-				part_round<kPartThreads, kPartHalf * H, WINDOW ? 1 : H>(pl, out, 0, blockIdx.x, bin, val, live, ovf STAMP_PASS);
+				if (SMALL) {
+					// the next tile's words (requested at the top of this tile) are pinned in their registers
+					// before each flush issues its stores (in both rounds, so that on no path the compiler
+					// still sees them in flight at the top of the next tile, behind the stores)
+					auto land = [&]() {
+#pragma unroll
+						for (int q = 0; q < kPartW / 4 + 1; ++q)
+							asm volatile("" : "+v"(raw.w[q]));
+					};
+					part_round_s<kPartHalf * H, WINDOW ? 1 : H>(ps, out, blockIdx.x, bin, val, live, ovf, land STAMP_PASS);
+				}
+				else
+					part_round<kPartThreads, kPartHalf * H, WINDOW ? 1 : H>(pl, out, 0, blockIdx.x, bin, val, live, ovf STAMP_PASS);
 			}
 		});
 		if (a.valid_bits || a.hit_bits) {
@@ -108,7 +169,10 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 		}
 		my_valid += __popc(vmask);
 	}
-	part_finish<kPartThreads>(pl, out, 0, blockIdx.x, ovf);
+	if (SMALL)
+		part_finish_s(ps, out, blockIdx.x, ovf);
+	else
+		part_finish<kPartThreads>(pl, out, 0, blockIdx.x, ovf);
 	if (a.counts) {
 		const uint32_t wv = wave_sum(my_valid);
 		if ((tid & 63) == 0 && wv)
@@ -118,20 +182,21 @@ __global__ __launch_bounds__(kPartThreads) void part_hash_kernel(const SeqArgs a
 	STAMP_FLUSH;
 }
 
-template <int H, bool Q>
+template <int H, bool Q, bool SMALL>
 static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd,
                                 size_t dyn, hipStream_t s)
 {
 	const bool pow2 = a.mod.pow2 != 0, spaced = a.hp.n_seeds > 0;
 	const bool window = a.mod.shard_lo != 0 || a.mod.shard_len != a.mod.size;
-#define BTLBF_PLAUNCH(P, S, W)                                                                                  \
-	do {                                                                                                        \
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_kernel<H, P, S, Q, W>),       \
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                \
-		if (e != hipSuccess)                                                                                    \
-			return e;                                                                                           \
-		hipLaunchKernelGGL((part_hash_kernel<H, P, S, Q, W>), dim3(out.regions), dim3(kPartThreads), dyn, s, a, \
-		                   out, bin_shift, sd);                                                                 \
+	constexpr int NT = SMALL ? kPartThreadsS : kPartThreads;
+#define BTLBF_PLAUNCH(P, S, W)                                                                                      \
+	do {                                                                                                            \
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_kernel<H, P, S, Q, W, SMALL>),    \
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                    \
+		if (e != hipSuccess)                                                                                        \
+			return e;                                                                                               \
+		hipLaunchKernelGGL((part_hash_kernel<H, P, S, Q, W, SMALL>), dim3(out.regions), dim3(NT), dyn, s, a, out,    \
+		                   bin_shift, sd);                                                                          \
 	} while (0)
 #define BTLBF_PLAUNCH_W(P, S)        \
 	do {                             \
@@ -157,10 +222,14 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t b
 #define BTLBF_CAT2(a, b) a##b
 #define BTLBF_CAT(a, b) BTLBF_CAT2(a, b)
 hipError_t BTLBF_CAT(launch_part_hash_h, BTLBF_PART_H)(const SeqArgs& a, const PartOut& out, uint32_t bin_shift,
-                                                       const PartSide& sd, size_t dyn, int query, hipStream_t s)
+                                                       const PartSide& sd, size_t dyn, int query, int small,
+                                                       hipStream_t s)
 {
-	return query ? launch_hash_h<BTLBF_PART_H, true>(a, out, bin_shift, sd, dyn, s)
-	             : launch_hash_h<BTLBF_PART_H, false>(a, out, bin_shift, sd, dyn, s);
+	if (small)
+		return query ? launch_hash_h<BTLBF_PART_H, true, true>(a, out, bin_shift, sd, dyn, s)
+		             : launch_hash_h<BTLBF_PART_H, false, true>(a, out, bin_shift, sd, dyn, s);
+	return query ? launch_hash_h<BTLBF_PART_H, true, false>(a, out, bin_shift, sd, dyn, s)
+	             : launch_hash_h<BTLBF_PART_H, false, false>(a, out, bin_shift, sd, dyn, s);
 }
 
 #if defined(BTLBF_PHASE_STAMPS) && BTLBF_PART_H == 4

@@ -148,11 +148,15 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	__syncthreads();
 	STAMP(4);
 	{
-		// bins are owned by lanes (P <= NT): wave v owns bins [64v, 64v+64) and flushes them itself,
-		// through its private slice of the flush list -- no workgroup barrier in between
-		const uint32_t b = tid, lane = tid & 63;
+		// bins are owned by lanes (P <= NT), spread evenly over the waves: wave v owns bins [v*bpw, (v+1)*bpw),
+		// bpw = ceil(P / waves) <= 64, and flushes them itself through its private slice of the flush list --
+		// no workgroup barrier in between (with 512 bins every one of the 16 waves flushes 32 bins, instead
+		// of eight waves flushing 64 each while the other eight wait at the barrier)
+		const uint32_t lane = tid & 63;
+		const uint32_t bpw = (P + NT / 64 - 1) / (NT / 64);
+		const uint32_t b = (tid >> 6) * bpw + lane;
 		uint32_t nfl = 0, rd0 = 0, w0 = 0;
-		if (b < P) {
+		if (lane < bpw && b < P) {
 			const uint32_t w = l.pt[b];
 			const uint32_t occ = w & 0xffffu;           // ring content + everything offered this round
 			const uint32_t avail = occ < SC ? occ : SC; // entries that really sit in the ring
@@ -173,7 +177,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 		// in the wave's slice (64 bins * SC/kChunk items)
 		const uint32_t incl = wave_scan_incl(nfl);
 		const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-		const uint32_t slice = (tid >> 6) * ((64u / kChunk) << l.sc_shift);
+		const uint32_t slice = (tid >> 6) * ((bpw << l.sc_shift) >> kChunkShift);
 		for (uint32_t c = 0; c < nfl; ++c) {
 			const uint32_t j = slice + incl - nfl + c;
 			l.flist[j] = (uint16_t)(b | ((((rd0 >> kChunkShift) + c) & (ring >> kChunkShift)) << 10));
@@ -250,6 +254,194 @@ __device__ __forceinline__ void part_finish(const PartLds& l, const PartOut& o, 
 	}
 }
 
+// ---- the small geometry: two 512-thread workgroups per CU (pass A with 257..512 level-0 bins) ----------
+// One 1024-thread workgroup per CU runs its phases in lockstep: while every wave waits on LDS atomics the
+// SIMDs idle, while every wave hashes the LDS idles, and a barrier stalls the whole CU.  Two independent
+// workgroups per CU (80 KiB of LDS each) let the hardware overlap one's hashing with the other's LDS and
+// barrier phases.  Each has 64 KiB of rings: 32 entries per bin, flushed in 64-byte chunks of 16 entries
+// (a 32-entry ring cannot work with 32-entry chunks: up to 31 left-over entries plus one round's ~16 new
+// ones).  Regions are still counted in 128-byte units (PartOut::cap), so readers see no difference.
+static constexpr int kPartThreadsS = 512;
+static constexpr uint32_t kStageEntriesS = 16384;
+static constexpr uint32_t kRingS = 32, kRingShiftS = 5; // entries per bin ring
+static constexpr uint32_t kChunkS = 16, kChunkShiftS = 4;
+static constexpr uint32_t kPartMinBinsS = 257, kPartMaxBinsS = 512;
+static constexpr uint32_t kPartLdsBudgetS = 80 * 1024 - 1536; // dynamic LDS per workgroup at two per CU
+
+struct PartLdsS {
+	uint32_t* stage;   // [512][32]
+	uint32_t* pt;      // [P] as PartLds::pt
+	uint32_t* written; // [P] 16-entry chunks written to this workgroup's region of the bin
+	uint16_t* fl;      // [P] entries flushed from the bin this round
+};
+
+__host__ __device__ inline uint32_t part_lds_bytes_s(uint32_t P) { return kStageEntriesS * 4 + P * 10 + 16; }
+
+__device__ __forceinline__ PartLdsS part_carve_s(uint8_t* base, uint32_t P)
+{
+	PartLdsS l;
+	l.stage = reinterpret_cast<uint32_t*>(base);
+	l.pt = l.stage + kStageEntriesS;
+	l.written = l.pt + P;
+	l.fl = reinterpret_cast<uint16_t*>(l.written + P);
+	return l;
+}
+
+__device__ __forceinline__ void part_init_s(const PartLdsS& l, uint32_t P)
+{
+	for (uint32_t b = threadIdx.x; b < P; b += kPartThreadsS) {
+		l.pt[b] = 0;
+		l.written[b] = 0;
+		l.fl[b] = 0;
+	}
+}
+
+// part_round for the small geometry (same three phases and the same pt[] protocol).  Lane b owns bin b
+// (P <= 512 = threads); a bin flushes at most two chunks per round.  The flush work of a wave's 64 bins is
+// compacted WITHOUT an LDS list: owners push their bin's data to lane `rank` with ds_permute (first
+// chunks, then second chunks), and four lanes copy each 64-byte chunk.
+// `pre_flush()` runs between the first barrier and the chunk stores (pass A pins the arrival of the next
+// tile's prefetched words there: vector-memory operations retire in order, so waiting for those loads
+// AFTER a flush would wait for the flush's stores as well).
+template <int E, int G, class OVF, class PRE>
+__device__ __forceinline__ void part_round_s(const PartLdsS& l, const PartOut& o, uint32_t region,
+                                             const uint32_t (&bin)[E], const uint32_t (&val)[E], const uint32_t live,
+                                             OVF&& ovf, PRE&& pre_flush STAMP_ARGS)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint32_t P = o.P;
+	constexpr uint32_t SC = kRingS, ring = kRingS - 1;
+	uint32_t old[E];
+	uint32_t late = 0;
+	static_assert(E <= 32 && E % G == 0, "one flag bit per entry; whole groups");
+#pragma unroll
+	for (int g = 0; g < E / G; ++g) {
+		if ((live >> g) & 1) {
+#pragma unroll
+			for (int e = g * G; e < (g + 1) * G; ++e)
+				old[e] = atomicAdd(&l.pt[bin[e]], 0x10001u);
+		}
+	}
+#pragma unroll
+	for (int g = 0; g < E / G; ++g) {
+		if ((live >> g) & 1) {
+#pragma unroll
+			for (int e = g * G; e < (g + 1) * G; ++e) {
+				if ((old[e] & 0xffffu) < SC)
+					l.stage[(bin[e] << kRingShiftS) + ((old[e] >> 16) & ring)] = val[e];
+				else
+					late |= 1u << e;
+			}
+		}
+	}
+	__syncthreads();
+	STAMP(4);
+	pre_flush();
+	{
+		const uint32_t b = tid, lane = tid & 63;
+		uint32_t nfl = 0, rd0 = 0, w0 = 0;
+		if (b < P) {
+			const uint32_t w = l.pt[b];
+			const uint32_t occ = w & 0xffffu;
+			const uint32_t avail = occ < SC ? occ : SC;
+			nfl = avail >> kChunkShiftS; // 0..2
+			const uint32_t f = nfl << kChunkShiftS;
+			const uint32_t tot = occ - f;
+			const uint32_t nocc = tot < SC ? tot : SC;
+			l.pt[b] = (((w >> 16) - (tot - nocc)) << 16) | nocc;
+			l.fl[b] = (uint16_t)f;
+			if (nfl) {
+				w0 = l.written[b];
+				l.written[b] = w0 + nfl;
+				rd0 = ((w >> 16) - occ) & ring; // multiple of 16: chunks leave whole
+			}
+		}
+		// compaction: list 1 = bins flushing at least one chunk, list 2 = bins flushing two
+		const uint64_t m1 = __ballot(nfl >= 1), m2 = __ballot(nfl >= 2);
+		const uint32_t n1 = __popcll(m1), n2 = __popcll(m2);
+		const uint32_t below = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0));
+		const uint32_t below2 = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0));
+		// item = bin-in-wave | first ring chunk << 8 ; region chunk index
+		const uint32_t item = lane | ((rd0 >> kChunkShiftS) << 8);
+		// every lane pushes (ds_permute delivers only to active lanes): owners with work to their rank, the
+		// others behind the list -- a full permutation, so no two lanes push to the same place
+		const uint32_t d1 = nfl >= 1 ? below : n1 + lane - below;
+		const uint32_t d2 = nfl >= 2 ? below2 : n2 + lane - below2;
+		const uint32_t it1 = (uint32_t)__builtin_amdgcn_ds_permute((int)(d1 << 2), (int)item);
+		const uint32_t wc1 = (uint32_t)__builtin_amdgcn_ds_permute((int)(d1 << 2), (int)w0);
+		const uint32_t it2 = (uint32_t)__builtin_amdgcn_ds_permute((int)(d2 << 2), (int)(item ^ 0x100u)); // the ring's other chunk
+		const uint32_t wc2 = (uint32_t)__builtin_amdgcn_ds_permute((int)(d2 << 2), (int)(w0 + 1));
+		// lanes [0, n1) of it1/wc1 and [0, n2) of it2/wc2 now hold the lists
+		constexpr uint32_t kLanesPerChunk = kChunkS / 4; // 16 bytes per lane
+		const uint32_t l4 = lane & (kLanesPerChunk - 1), q = lane / kLanesPerChunk;
+		const uint32_t cap_s = o.cap * (kChunk / kChunkS);
+		const uint32_t wave_bin0 = tid & ~63u;
+		auto copy_list = [&](uint32_t items, uint32_t wcs, uint32_t n) {
+			for (uint32_t j0 = 0; j0 < n; j0 += 64 / kLanesPerChunk) {
+				const uint32_t j = j0 + q;
+				const uint32_t it = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)items);
+				const uint32_t wc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)wcs);
+				if (j < n) {
+					const uint32_t fb = wave_bin0 + (it & 63u), rc = (it >> 8) & 1u;
+					const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(fb << kRingShiftS) + (rc << kChunkShiftS) + l4 * 4]);
+					if (wc < cap_s) {
+						const uint64_t dst = ((uint64_t)(fb * o.regions + region) * cap_s + wc) * kChunkS + l4 * 4;
+						*reinterpret_cast<uint4*>(&o.ent[dst]) = v;
+					} else {
+						ovf(fb, v.x);
+						ovf(fb, v.y);
+						ovf(fb, v.z);
+						ovf(fb, v.w);
+					}
+				}
+			}
+		};
+		copy_list(it1, wc1, n1);
+		copy_list(it2, wc2, n2);
+	}
+	__syncthreads();
+	STAMP(6);
+	if (late) {
+#pragma unroll
+		for (int e = 0; e < E; ++e) {
+			if ((late >> e) & 1) {
+				if ((old[e] & 0xffffu) - l.fl[bin[e]] < SC)
+					l.stage[(bin[e] << kRingShiftS) + ((old[e] >> 16) & ring)] = val[e];
+				else
+					ovf(bin[e], val[e]);
+			}
+		}
+	}
+	STAMP(7);
+}
+
+// flush what is staged (at most a ring = 32 entries per bin) and publish the exact entry counts
+template <class OVF>
+__device__ __forceinline__ void part_finish_s(const PartLdsS& l, const PartOut& o, uint32_t region, OVF&& ovf)
+{
+	__syncthreads();
+	const uint32_t tid = threadIdx.x, ln = tid & (kRingS - 1);
+	const uint32_t cap_e = o.cap * kChunk;
+	for (uint32_t b = tid / kRingS; b < o.P; b += kPartThreadsS / kRingS) {
+		const uint32_t w = l.pt[b], n = w & 0xffffu, hd = ((w >> 16) - n) & (kRingS - 1);
+		const uint64_t base_e = (uint64_t)l.written[b] * kChunkS;
+		const uint64_t o0 = (uint64_t)(b * o.regions + region) * cap_e;
+		// the tail is padded to a whole 16-byte vector with copies of the last entry (see part_finish)
+		if (n && ln < ((n + 3) & ~3u)) {
+			const uint32_t v = l.stage[(b << kRingShiftS) + ((hd + (ln < n ? ln : n - 1)) & (kRingS - 1))];
+			if (base_e + ln < cap_e)
+				o.ent[o0 + base_e + ln] = v;
+			else if (ln < n)
+				ovf(b, v);
+		}
+		if (ln == 0) {
+			const uint64_t full = base_e < cap_e ? base_e : cap_e;
+			const uint64_t room = cap_e - full;
+			o.cnt[b * o.regions + region] = (uint32_t)(full + (n < room ? n : room));
+		}
+	}
+}
+
 // where the overflow entries of the routing passes go (multi-GPU): global positions
 __device__ __forceinline__ void part_spill(const PartSide& sd, uint64_t pos)
 {
@@ -284,9 +476,10 @@ __device__ __forceinline__ void part_direct(uint32_t* words, const PartSide& sd,
 
 
 // pass A launchers, one translation unit per hash count (part_hash_inst.hip, -DBTLBF_PART_H=n)
+// small != 0: the two-workgroups-per-CU geometry (512 threads, tiles of 4096 windows)
 #define BTLBF_DECL_HASH_LAUNCH(n)                                                                              \
 	hipError_t launch_part_hash_h##n(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd, \
-	                                 size_t dyn, int query, hipStream_t s);
+	                                 size_t dyn, int query, int small, hipStream_t s);
 BTLBF_DECL_HASH_LAUNCH(1)
 BTLBF_DECL_HASH_LAUNCH(2)
 BTLBF_DECL_HASH_LAUNCH(3)

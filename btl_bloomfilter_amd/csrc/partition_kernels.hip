@@ -24,6 +24,8 @@
 // one flush hold inside one round) take the overflow path: applied to the filter directly (single
 // GPU) or appended to a spill list of global positions (multi-GPU routing) -- never dropped.
 #include "partition_core.hpp"
+#include <cstdlib>
+#include <cstring>
 
 namespace btlbf {
 
@@ -297,58 +299,112 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
-int part_tile_windows() { return kPartTile; }
+// How pass A's front end is set up for one (hash configuration, level-0 bins): geometry, whether the
+// positional seed table is used, and the dynamic LDS all of it needs.
+struct PartFront {
+	bool small = false;  // two 512-thread workgroups per CU (partition_core.hpp)
+	uint32_t nt = kPartThreads;
+	uint32_t use_pos_tab = 0;
+	uint32_t dyn = 0;
+};
 
-uint32_t part_hash_lds_bytes(const HashParams& hp, uint32_t p0)
+// The small geometry is opt-in (BTLBF_PART_GEOM=small): measured on MI355X at C2 it is no faster than one
+// 1024-thread workgroup -- pass A is bound by VALU issue, not by the latencies a second workgroup would
+// hide.
+static bool part_want_small(uint32_t p0)
 {
-	return seq_tile_cap(kPartTile, hp.k) + seq_spaced_bytes(hp) + part_lds_bytes(p0);
+	if (p0 < kPartMinBinsS || p0 > kPartMaxBinsS)
+		return false;
+	const char* e = getenv("BTLBF_PART_GEOM");
+	return e && !strcmp(e, "small");
 }
 
-// can pass A run for this hash configuration at all (possibly without the positional table)?
-bool part_hash_fits(const HashParams& hp_in, uint32_t p0)
+// with the positional seed table if it fits, else without (Horner start-up; spaced seeds cannot do without it)
+static bool part_front(const HashParams& hp_in, uint32_t p0, PartFront& fr)
 {
-	HashParams hp = hp_in;
-	if (part_hash_lds_bytes(hp, p0) <= kPartLdsBudget)
-		return true;
-	if (hp.n_seeds)
-		return false;
-	hp.use_pos_tab = 0;
-	return part_hash_lds_bytes(hp, p0) <= kPartLdsBudget;
+	for (int geom = part_want_small(p0) ? 1 : 0; geom >= 0; --geom) {
+		fr.small = geom == 1;
+		fr.nt = fr.small ? kPartThreadsS : kPartThreads;
+		const uint32_t rings = fr.small ? part_lds_bytes_s(p0) : part_lds_bytes(p0);
+		const uint32_t budget = fr.small ? kPartLdsBudgetS : kPartLdsBudget;
+		for (int tab = 1; tab >= 0; --tab) {
+			HashParams hp = hp_in;
+			if (!tab) {
+				if (hp.n_seeds || !hp.use_pos_tab)
+					break;
+				hp.use_pos_tab = 0;
+			}
+			const uint32_t dyn = seq_tile_cap(fr.nt * kPartW, hp.k) + seq_spaced_bytes(hp) + rings;
+			if (dyn <= budget) {
+				fr.use_pos_tab = hp.use_pos_tab;
+				fr.dyn = dyn;
+				return true;
+			}
+		}
+	}
+	return false;
+}
+
+// can pass A run for this hash configuration at all?
+bool part_hash_fits(const HashParams& hp, uint32_t p0)
+{
+	PartFront fr;
+	return part_front(hp, p0, fr);
+}
+
+// workgroups (= regions per bin) pass A wants for `cus` compute units
+uint32_t part_hash_regions(const HashParams& hp, uint32_t p0, uint32_t cus)
+{
+	PartFront fr;
+	return part_front(hp, p0, fr) && fr.small ? 2 * cus : cus;
+}
+
+// how pass A cuts a buffer into tiles; all host-side planning is in these units
+PartTiling part_tiling(const HashParams& hp, uint32_t p0, const LayoutParams& lay, uint64_t len)
+{
+	PartFront fr;
+	if (!part_front(hp, p0, fr))
+		fr = PartFront();
+	PartTiling t;
+	const uint32_t L = lay.starts ? 0 : lay.read_len;
+	t.tile_bytes = fr.nt * kPartW;
+	t.n_tiles = (len + t.tile_bytes - 1) / t.tile_bytes;
+	t.windows_per_tile = (double)t.tile_bytes * (L ? (L >= hp.k ? (double)(L - hp.k + 1) / L : 0.0) : 1.0);
+	return t;
 }
 
 static hipError_t launch_hash_any(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd,
-                                  size_t dyn, int query, hipStream_t s)
+                                  size_t dyn, int query, int small, hipStream_t s)
 {
 	switch (a.hp.h) {
-	case 1: return launch_part_hash_h1(a, out, bin_shift, sd, dyn, query, s);
-	case 2: return launch_part_hash_h2(a, out, bin_shift, sd, dyn, query, s);
-	case 3: return launch_part_hash_h3(a, out, bin_shift, sd, dyn, query, s);
-	case 4: return launch_part_hash_h4(a, out, bin_shift, sd, dyn, query, s);
-	case 5: return launch_part_hash_h5(a, out, bin_shift, sd, dyn, query, s);
-	case 6: return launch_part_hash_h6(a, out, bin_shift, sd, dyn, query, s);
-	case 7: return launch_part_hash_h7(a, out, bin_shift, sd, dyn, query, s);
-	case 8: return launch_part_hash_h8(a, out, bin_shift, sd, dyn, query, s);
+	case 1: return launch_part_hash_h1(a, out, bin_shift, sd, dyn, query, small, s);
+	case 2: return launch_part_hash_h2(a, out, bin_shift, sd, dyn, query, small, s);
+	case 3: return launch_part_hash_h3(a, out, bin_shift, sd, dyn, query, small, s);
+	case 4: return launch_part_hash_h4(a, out, bin_shift, sd, dyn, query, small, s);
+	case 5: return launch_part_hash_h5(a, out, bin_shift, sd, dyn, query, small, s);
+	case 6: return launch_part_hash_h6(a, out, bin_shift, sd, dyn, query, small, s);
+	case 7: return launch_part_hash_h7(a, out, bin_shift, sd, dyn, query, small, s);
+	case 8: return launch_part_hash_h8(a, out, bin_shift, sd, dyn, query, small, s);
 	default: return hipErrorInvalidValue;
 	}
 }
 
 bool part_supported_h(uint32_t h) { return h >= 1 && h <= 8; }
 
-// pass A over tiles [a.first_tile, +a.n_tiles) (units: kPartTile windows); exactly out.regions
-// workgroups are launched (one region each; idle ones still publish empty counts)
+// pass A over tiles [a.first_tile, +a.n_tiles) in the units of part_tiling() for this buffer; exactly
+// out.regions workgroups are launched (one region each; idle ones still publish empty counts)
 hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bin_shift, const PartSide& sd,
                             int query, hipStream_t s)
 {
 	SeqArgs a = a_in;
 	if (a.n_tiles == 0)
 		return hipSuccess;
-	// LDS is nearly full with the staging rings: drop the positional table (Horner start-up
-	// instead) when it does not fit; spaced seeds cannot do without it
-	if (a.hp.n_seeds == 0 && part_hash_lds_bytes(a.hp, out.P) > kPartLdsBudget)
-		a.hp.use_pos_tab = 0;
+	PartFront fr;
+	if (!part_front(a.hp, out.P, fr))
+		return hipErrorInvalidValue;
+	a.hp.use_pos_tab = fr.use_pos_tab;
 	a.tiles_per_block = (a.n_tiles + out.regions - 1) / out.regions;
-	const size_t dyn = part_hash_lds_bytes(a.hp, out.P);
-	return launch_hash_any(a, out, bin_shift, sd, dyn, query, s);
+	return launch_hash_any(a, out, bin_shift, sd, fr.dyn, query, fr.small, s);
 }
 
 hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_in, uint32_t abs_first, uint32_t n_in_bins,

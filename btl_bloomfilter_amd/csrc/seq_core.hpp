@@ -122,19 +122,24 @@ struct StageRaw {
 // Request this thread's words of the tile that starts at byte offset g0 (zero past the data).  Kept
 // apart from the conversion so that a kernel can have the NEXT tile's loads in flight while it works
 // on the current one (pass A of the partitioned pipeline).
+// span = bytes a tile stages (0: the NT*KW window starts plus the k-1 bases behind the last one)
 template <int NT, int KW = kW>
 __device__ __forceinline__ void seq_stage_load(StageRaw<KW>& raw, const uint8_t* seq, uint64_t len, uint32_t k,
-                                               uint64_t g0)
+                                               uint64_t g0, uint32_t span = 0)
 {
 	constexpr uint32_t kTileW = NT * KW;
+	if (span == 0)
+		span = kTileW + k - 1;
 	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(seq + g0) & 3);
 	uint64_t need = len > g0 ? len - g0 : 0;
-	if (need > (uint64_t)(kTileW + k - 1))
-		need = kTileW + k - 1;
+	if (need > (uint64_t)span)
+		need = span;
 	const uint32_t n_words = need ? (mis + (uint32_t)need + 3) / 4 : 0;
+	uint32_t tid = threadIdx.x; // laundered: see seq_stage_convert
+	asm volatile("" : "+v"(tid));
 #pragma unroll
 	for (int a = 0; a < KW / 4 + 1; ++a) {
-		const uint32_t j = threadIdx.x + (uint32_t)a * NT;
+		const uint32_t j = tid + (uint32_t)a * NT;
 		raw.w[a] = 0;
 		if (j < n_words)
 			raw.w[a] = *reinterpret_cast<const uint32_t*>(seq + g0 - mis + 4ull * j);
@@ -153,16 +158,22 @@ template <int NT, int KW = kW, bool LEAD_BARRIER = true, bool TRAIL_BARRIER = tr
 __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, uint8_t* tile, uint32_t tile_cap,
                                                       SeqShared& sh, const uint8_t* seq, uint64_t len,
                                                       const LayoutParams& lay, uint32_t k, uint64_t g0,
-                                                      uint32_t tile_off)
+                                                      uint32_t tile_off, uint32_t span = 0)
 {
 	constexpr uint32_t kTileW = NT * KW;
-	const uint32_t tid = threadIdx.x;
+	if (span == 0)
+		span = kTileW + k - 1;
+	// the thread index is laundered so that the per-word LDS addresses below are recomputed every tile: left
+	// to itself the compiler hoists them out of the caller's tile loop into registers it then has to spill,
+	// and in pass A a scratch reload sits behind the previous flush's stores (vector memory retires in order)
+	uint32_t tid = threadIdx.x;
+	asm volatile("" : "+v"(tid));
 	const uint32_t L = lay.read_len;
 	const uint64_t* starts = lay.starts;
 	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(seq + g0) & 3);
-	uint64_t need = len - g0;
-	if (need > (uint64_t)(kTileW + k - 1))
-		need = kTileW + k - 1;
+	uint64_t need = len > g0 ? len - g0 : 0;
+	if (need > (uint64_t)span)
+		need = span;
 	const uint32_t n_words = (mis + (uint32_t)need + 3) / 4;
 	const bool uniform = !starts && L;
 	const uint32_t inv = uniform ? 0xffffffffu / L : 0;
@@ -180,8 +191,17 @@ __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, u
 		uint32_t keep = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1);
 		if (lo)
 			keep &= lo >= 4 ? 0u : ~((1u << (8 * lo)) - 1);
-		uint32_t o = (uint32_t)sh.lut[raw & 0xff] | ((uint32_t)sh.lut[(raw >> 8) & 0xff] << 8) |
-		             ((uint32_t)sh.lut[(raw >> 16) & 0xff] << 16) | ((uint32_t)sh.lut[raw >> 24] << 24);
+		// fast path, four bases at once: (c >> 1) & 3 sends A C T G (either case) to 0 1 2 3; a byte permute
+		// maps that index back to the letter it must have come from -- the word holds nothing but ACGT/acgt
+		// iff the case-folded word equals that -- and a second one to the staged byte (code << 4 | valid |
+		// good).  Anything else (N, U, the raw bytes 1 3 4 5 7, padding) takes the LUT.
+		const uint32_t idx = (raw >> 1) & 0x03030303u;
+		uint32_t o;
+		if ((raw & 0xdfdfdfdfu) == __builtin_amdgcn_perm(0u, 0x47544341u, idx))
+			o = __builtin_amdgcn_perm(0u, 0x23331303u, idx);
+		else
+			o = (uint32_t)sh.lut[raw & 0xff] | ((uint32_t)sh.lut[(raw >> 8) & 0xff] << 8) |
+			    ((uint32_t)sh.lut[(raw >> 16) & 0xff] << 16) | ((uint32_t)sh.lut[raw >> 24] << 24);
 		o &= keep;
 		if (uniform) {
 			// offset of the word's first byte inside its read; a read of >= 4 bases starts at most once

@@ -18,8 +18,15 @@ def _is_torch_cuda(x):
     return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
 
 
-def _stream_ptr(stream):
+def _stream_ptr(stream, buf=None):
+    """hipStream_t for a call.  stream=None with a torch CUDA buffer means torch's CURRENT stream on that
+    device (the stream the buffer's producer and the output zero-fills are ordered on), not the legacy
+    NULL stream, which torch's non-blocking side streams do not synchronise with."""
     if stream is None:
+        if buf is not None and _is_torch_cuda(buf):
+            import torch
+
+            return C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)
         return None
     return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
 
@@ -150,6 +157,13 @@ class _Filter:
         a = np.ascontiguousarray(body, np.uint8)
         check(self._L.btlbf_upload(self._h, C.c_void_p(a.ctypes.data), 0, a.nbytes))
 
+    def compare(self, other):
+        """(positions that differ, positions where self > other, where self < other) against another filter
+        of the same geometry, computed in HBM (btlbf_compare); positions are bits or uint8_t counters"""
+        out = (C.c_uint64 * 3)()
+        check(self._L.btlbf_compare(self._h, other._h, out))
+        return tuple(out)
+
     def setInsertMode(self, mode, scratch_bytes=0):
         """'auto' | 'direct' | 'partitioned' (see btlbf_set_insert_mode)"""
         m = {"auto": 0, "direct": 1, "partitioned": 2}[mode] if isinstance(mode, str) else int(mode)
@@ -212,7 +226,7 @@ class _Filter:
             cnt = np.zeros(2, np.uint64) if want_counts else None
             ptr = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None  # noqa: E731
         check(fn(self._h, b.ptr, n, C.byref(lay) if lay else None, ptr(hit), ptr(valid), ptr(cnt), b.mem,
-                 _stream_ptr(stream)))
+                 _stream_ptr(stream, b.keep)))
         return hit, valid, cnt
 
     def containsSeqs(self, seq, starts=None, read_len=0, want_valid=True, want_counts=False, stream=None):
@@ -223,7 +237,7 @@ class _Filter:
         b = _Buf(seq)
         lay, keep = _layout(starts, read_len, b.mem)
         check(self._L.btlbf_insert_seqs(self._h, b.ptr, b.nbytes, C.byref(lay) if lay else None, op, order,
-                                        b.mem, _stream_ptr(stream)))
+                                        b.mem, _stream_ptr(stream, b.keep)))
 
     # -- hash rows -----------------------------------------------------------------------------
     def _rows(self, hashes):
@@ -244,7 +258,7 @@ class _Filter:
         else:
             out = np.zeros(max(n, 1), np.uint8)
             optr = C.c_void_p(out.ctypes.data)
-        check(fn(self._h, b.ptr, n, optr, *extra, b.mem, _stream_ptr(stream)))
+        check(fn(self._h, b.ptr, n, optr, *extra, b.mem, _stream_ptr(stream, b.keep)))
         return out[:n]
 
 
@@ -295,7 +309,7 @@ class BloomFilter(_Filter):
     # batch forms of insert / contains / insertAndCheck over hash rows
     def insert(self, hashes, stream=None):
         b, n = self._rows(hashes)
-        check(self._L.btlbf_insert_hashes(self._h, b.ptr, n, 0, ORDER_PARALLEL, b.mem, _stream_ptr(stream)))
+        check(self._L.btlbf_insert_hashes(self._h, b.ptr, n, 0, ORDER_PARALLEL, b.mem, _stream_ptr(stream, b.keep)))
 
     def contains(self, hashes, stream=None):
         return self._rows_out(self._L.btlbf_contains_hashes, hashes, stream=stream)
@@ -399,12 +413,14 @@ class CountingBloomFilter(_Filter):
     def incrementMin(self, hashes, serial=False, stream=None):
         b, n = self._rows(hashes)
         check(self._L.btlbf_insert_hashes(self._h, b.ptr, n, INCREMENT_MIN,
-                                          ORDER_SERIAL if serial else ORDER_PARALLEL, b.mem, _stream_ptr(stream)))
+                                          ORDER_SERIAL if serial else ORDER_PARALLEL, b.mem,
+                                          _stream_ptr(stream, b.keep)))
 
     def incrementAll(self, hashes, serial=False, stream=None):
         b, n = self._rows(hashes)
         check(self._L.btlbf_insert_hashes(self._h, b.ptr, n, INCREMENT_ALL,
-                                          ORDER_SERIAL if serial else ORDER_PARALLEL, b.mem, _stream_ptr(stream)))
+                                          ORDER_SERIAL if serial else ORDER_PARALLEL, b.mem,
+                                          _stream_ptr(stream, b.keep)))
 
     def minCount(self, hashes, stream=None):
         return self._rows_out(self._L.btlbf_min_count_hashes, hashes, stream=stream)
@@ -435,7 +451,7 @@ class CountingBloomFilter(_Filter):
             valid = _bitmap(n)
             p1, p2 = C.c_void_p(mn.ctypes.data), C.c_void_p(valid.ctypes.data)
         check(self._L.btlbf_min_count_seqs(self._h, b.ptr, n, C.byref(lay) if lay else None, p1, p2, b.mem,
-                                           _stream_ptr(stream)))
+                                           _stream_ptr(stream, b.keep)))
         return mn[:n], valid
 
 
@@ -462,7 +478,7 @@ def _hash_seqs(seq, k, h, seeds, h2, starts, read_len, device, stream):
         st = np.zeros(max(n, 1), np.uint64) if seeds is not None else None
         ptr = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None  # noqa: E731
     check(L.btlbf_hash_seqs(k, h, sarr, ns, h2, b.ptr, n, C.byref(lay) if lay else None, ptr(hv), ptr(valid),
-                            ptr(st), b.mem, device, _stream_ptr(stream)))
+                            ptr(st), b.mem, device, _stream_ptr(stream, b.keep)))
     return hv[:n], valid, (st[:n] if st is not None else None)
 
 
@@ -485,7 +501,7 @@ def synth_reads_device(seed, first, n_reads, read_len, device=0, stream=None):
 
     out = torch.empty(n_reads * read_len, dtype=torch.uint8, device="cuda:%d" % device)
     check(_lib.load().btlbf_synth_reads(C.c_void_p(out.data_ptr()), seed, first, n_reads, read_len, device,
-                                        _stream_ptr(stream)))
+                                        _stream_ptr(stream, out)))
     return out
 
 
@@ -508,7 +524,7 @@ def count_per_seq(hit_bits, valid_bits, n_bytes, k, starts=None, read_len=0, dev
         hits, valid = np.zeros(n_seqs, np.uint32), np.zeros(n_seqs, np.uint32)
         p1, p2 = C.c_void_p(hits.ctypes.data), C.c_void_p(valid.ctypes.data)
     check(_lib.load().btlbf_count_per_seq(hb.ptr, vb.ptr if vb is not None else None, int(n_bytes), C.byref(lay), int(k),
-                                           p1, p2, hb.mem, device, _stream_ptr(stream)))
+                                           p1, p2, hb.mem, device, _stream_ptr(stream, hb.keep)))
     return hits, valid
 
 

@@ -220,6 +220,12 @@ int btlbf_hash_seqs(unsigned kmer_size, unsigned hash_num, const char* const* se
 int btlbf_popcount(btlbf_filter* f, uint64_t* out);
 int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out);
 
+/* Position-wise comparison of two filters of the same kind, size (and shard range) on one device, without
+ * leaving HBM -- what a caller of the reference does with two filter bodies and memcmp.  Bit filters:
+ * out3 = {bits that differ, bits set only in a, bits set only in b}; counting filters: {counters that
+ * differ, counters with a > b, counters with a < b}.  Synchronises the device. */
+int btlbf_compare(btlbf_filter* a, btlbf_filter* b, uint64_t* out3);
+
 /* ---- multi-GPU hash-range sharding ------------------------------------------------
  * The M-bit filter is cut into n_shards contiguous bit ranges; shard g (btlbf_create_shard) holds
  * positions [g*M/n, (g+1)*M/n).  Routing is by POSITION, so the concatenated shard bodies are the

@@ -1,0 +1,34 @@
+"""diagnostic: HIP-event time of pass A (part_hash_kernel) for one library build.
+
+    BTLBF_LIB=btl_bloomfilter_amd/libbtlbf_<tag>.so [BTLBF_PART_GEOM=large|small] python tools/passa_time.py [reads]
+
+Diagnostic builds (BTLBF_BUILD_TAG / BTLBF_CXXFLAGS=-DBTLBF_EXP_NOPART|-DBTLBF_EXP_NOHASH) leave out the
+partition or the hashing; their filters are wrong on purpose, only the time of pass A means anything."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from btl_bloomfilter_amd import _lib
+
+path = os.environ.get("BTLBF_LIB")
+if path:
+    _lib.LIB_PATH = os.path.abspath(path)
+    _lib.load(_lib.LIB_PATH)
+import torch
+
+import btl_bloomfilter_amd as m
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+L = int(os.environ.get("READ_LEN", 150))
+f = m.BloomFilter(1 << 39, 4, 31)
+f.setInsertMode("partitioned")
+f.setProfiling(True)
+reads = m.synth_reads_device(42, 0, n, L)
+for rep in range(3):
+    f.insertSeqs(reads, read_len=L)
+    torch.cuda.synchronize()
+    prof = f.getProfile()
+ms, calls = prof["insert_hash"]
+print("%-40s geom=%-6s pass A %.2f ms per launch (%d launches, %.2f ms per 1e9 k-mers)" % (
+    os.path.basename(path or "libbtlbf.so"), os.environ.get("BTLBF_PART_GEOM", "auto"), ms / calls, calls,
+    ms / (n * (L - 30) / 1e9)))

@@ -1,7 +1,10 @@
 """Quick timing of the fused insert / contains kernels on synthetic reads (not the contract bench)."""
 import json
+import os
 import sys
 import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
@@ -16,8 +19,9 @@ def main():
     f = m.BloomFilter(1 << lg, h, k)
     f.setInsertMode(mode)
     f.setQueryMode(sys.argv[4] if len(sys.argv) > 4 else "auto")
+    hit_only = len(sys.argv) > 5 and sys.argv[5] == "hitonly"  # skip the all-miss query (profiling runs)
     reads = m.synth_reads_device(42, 0, n_reads, L)
-    q = m.synth_reads_device(43, 0, n_reads, L)
+    q = reads if hit_only else m.synth_reads_device(43, 0, n_reads, L)
     torch.cuda.synchronize()
     kmers = n_reads * (L - k + 1)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]

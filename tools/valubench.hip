@@ -92,6 +92,7 @@ int main()
 	t[10] = run<10>(d, blocks);
 	t[11] = run<11>(d, blocks);
 	for (int i = 0; i < 12; ++i)
-		printf("%-16s %8.3f ms  cost relative to v_add_u32: %.2f\n", names[i], t[i], t[i] / t[0]);
+		printf("%-16s %8.3f ms  cost relative to v_add_u32: %.2f   %.3f wave-instructions per ns per SIMD\n", names[i], t[i],
+		       t[i] / t[0], (blocks * 4 / 1024.0) * ITER * 8 / (t[i] * 1e6));
 	return 0;
 }
