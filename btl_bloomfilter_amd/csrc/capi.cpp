@@ -1454,7 +1454,10 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 // A, regions = its CU count); the block of one owner is contiguous, so the exchange is a fixed-size
 // all-to-all of [B/W bins][regions][cap][kChunk] uint32 plus the entry counts.
 struct RoutePlan {
-	uint32_t bins = 1024; // level-0 bins over the global position space
+	uint32_t n_windows = 1;        // position windows routed one after the other (see route_plan)
+	uint32_t shards_per_window = 1;
+	uint32_t window_shift = 0;     // log2(positions per window)
+	uint32_t bins = 1024; // level-0 bins over ONE window of the global position space
 	uint32_t shift0 = 0;  // log2(positions per level-0 bin)
 	uint32_t bins_per_shard = 0;
 	uint32_t regions = 0;
@@ -1462,6 +1465,11 @@ struct RoutePlan {
 	uint64_t ent_bytes_per_shard = 0, cnt_bytes_per_shard = 0;
 };
 
+// An entry is the offset of a position inside its level-0 bin and has 32 bits; pass A stages at most 1024
+// bins.  So one routing pass covers at most 2^42 positions: a larger filter (C4: 2^43 bits on 8 GPUs) is
+// routed in WINDOWS of 2^42 positions, one pass A per window over the same reads (its WINDOW variant keeps
+// the probes inside the window; the hashing is repeated, the partitioning is not).  A window is owned by
+// n_shards / n_windows consecutive shards, and only they receive blocks of that window's pass.
 int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, unsigned n_shards, RoutePlan& rp)
 {
 	const uint64_t M = f->mod.size;
@@ -1469,25 +1477,37 @@ int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, uns
 		return fail(BTLBF_EINVAL, "routing needs a filter whose global size and shard count are powers of two");
 	if (!part_supported_h(f->hp.h) || !part_hash_fits(f->hp, 1024))
 		return fail(BTLBF_EINVAL, "routing does not support this hash configuration");
-	// 512 global level-0 bins (64-entry LDS rings at the origin: few late entries) as long as an entry
-	// -- the position's offset inside its bin -- fits 32 bits, else 1024.  BTLBF_ROUTE_BINS (power of
-	// two) exists for tests: fewer bins make small filters exercise the two-split and 32-bit-entry
-	// geometries of a 1 TiB filter on 8 GPUs
-	rp.bins = ceil_log2(M) - 9 <= 32 && n_shards <= 512 ? 512 : 1024;
+	const unsigned lm = ceil_log2(M);
+	unsigned max_window = 42; // BTLBF_ROUTE_WINDOW_BITS exists for tests: small filters then exercise several windows
+	if (const char* e = getenv("BTLBF_ROUTE_WINDOW_BITS")) {
+		const int v = atoi(e);
+		if (v >= 20 && v <= 42)
+			max_window = (unsigned)v;
+	}
+	rp.window_shift = std::min(lm, max_window);
+	rp.n_windows = 1u << (lm - rp.window_shift);
+	if (rp.n_windows > n_shards)
+		return fail(BTLBF_EINVAL, "routing a 2^%u-bit filter needs at least %u shards (windows of 2^%u positions)", lm,
+		            rp.n_windows, rp.window_shift);
+	rp.shards_per_window = n_shards / rp.n_windows;
+	// 512 level-0 bins per window (64-entry LDS rings at the origin: few late entries) as long as an entry
+	// fits 32 bits, else 1024.  BTLBF_ROUTE_BINS (power of two) exists for tests: fewer bins make small
+	// filters exercise the two-split and 32-bit-entry geometries of a 1 TiB filter on 8 GPUs
+	rp.bins = rp.window_shift - 9 <= 32 && rp.shards_per_window <= 512 ? 512 : 1024;
 	if (const char* e = getenv("BTLBF_ROUTE_BINS")) {
 		const unsigned b = (unsigned)atoi(e);
-		if (b >= n_shards && b <= 1024 && !(b & (b - 1)))
+		if (b >= rp.shards_per_window && b <= 1024 && !(b & (b - 1)))
 			rp.bins = b;
 	}
-	const unsigned lm = ceil_log2(M), lb = ceil_log2(rp.bins);
+	const unsigned lw = rp.window_shift, lb = ceil_log2(rp.bins);
 	const unsigned seg_min = f->kind == BTLBF_COUNTING8 ? 16 : 19; // positions in a 64 KiB segment
-	if (lm < lb + seg_min || lm - lb > 32 || rp.bins < n_shards)
-		return fail(BTLBF_EINVAL, "routing supports global filters of 2^29 .. 2^42 bits (2^26 .. 2^42 counters)");
-	rp.shift0 = lm - lb;
-	rp.bins_per_shard = rp.bins / n_shards;
+	if (lw < lb + seg_min || lw - lb > 32 || rp.bins < rp.shards_per_window)
+		return fail(BTLBF_EINVAL, "routing supports global filters of at least 2^29 bits (2^26 counters)");
+	rp.shift0 = lw - lb;
+	rp.bins_per_shard = rp.bins / rp.shards_per_window;
 	rp.regions = part_hash_regions(f->hp, rp.bins, cu_count(f->device));
 	const PartTiling tl = part_tiling(f->hp, rp.bins, lay, len);
-	const double entries = (double)tiles_for_caps(tl.n_tiles, rp.regions) * probes_per_tile(f, tl);
+	const double entries = (double)tiles_for_caps(tl.n_tiles, rp.regions) * probes_per_tile(f, tl) / rp.n_windows;
 	rp.cap = chunks_for(entries / ((double)rp.bins * rp.regions), 1);
 	rp.ent_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * rp.cap * (kChunk * 4);
 	rp.cnt_bytes_per_shard = (uint64_t)rp.bins_per_shard * rp.regions * 4;
@@ -1516,10 +1536,24 @@ extern "C" int btlbf_route_plan(btlbf_filter* f, uint64_t len, const btlbf_layou
 	return BTLBF_OK;
 }
 
+extern "C" int btlbf_route_windows(btlbf_filter* f, unsigned n_shards, unsigned* n_windows,
+                                   unsigned* shards_per_window)
+{
+	if (!f || !n_windows || !shards_per_window)
+		return fail(BTLBF_EINVAL, "null argument");
+	RoutePlan rp;
+	int rc = route_plan(f, 1, LayoutParams{nullptr, 0, 0}, n_shards, rp);
+	if (rc)
+		return rc;
+	*n_windows = rp.n_windows;
+	*shards_per_window = rp.shards_per_window;
+	return BTLBF_OK;
+}
+
 extern "C" int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
-                                uint64_t plan_len, unsigned n_shards, int query, void* send_ent, void* send_cnt,
-                                uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts, uint64_t* spill_list,
-                                uint64_t spill_cap, uint64_t* spill_count, void* stream)
+                                uint64_t plan_len, unsigned n_shards, unsigned window, int query, void* send_ent,
+                                void* send_cnt, uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts,
+                                uint64_t* spill_list, uint64_t spill_cap, uint64_t* spill_count, void* stream)
 {
 	int rc = seq_precheck(f, len);
 	if (rc)
@@ -1534,8 +1568,11 @@ extern "C" int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, 
 	RoutePlan rp;
 	if ((rc = route_plan(f, plan_len, v.lay, n_shards, rp)))
 		return rc;
+	if (window >= rp.n_windows)
+		return fail(BTLBF_EINVAL, "window %u of %u", window, rp.n_windows);
 	SeqArgs a = base_args(f, v, len);
-	fill_mod(a.mod, f->mod.size, 0, f->mod.size); // positions of the GLOBAL filter
+	// positions of the GLOBAL filter, those inside this window (all of them when there is one window)
+	fill_mod(a.mod, f->mod.size, (uint64_t)window << rp.window_shift, 1ull << rp.window_shift);
 	a.hit_bits = reinterpret_cast<uint8_t*>(hit_bits);
 	a.valid_bits = reinterpret_cast<uint8_t*>(valid_bits);
 	a.counts = counts;
@@ -1547,10 +1584,11 @@ extern "C" int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, 
 	sd.spill_list = spill_list;
 	sd.spill_count = reinterpret_cast<unsigned long long*>(spill_count);
 	sd.spill_cap = spill_cap;
+	sd.pos_base = a.mod.shard_lo; // spilled entries travel as global positions
 	// spill_count and counts ACCUMULATE over the batches of a pass (the caller zeroes them once): no
 	// host round trip per batch, so the exchange of one batch can overlap the hashing of the next
 	if (a.n_tiles == 0) { // nothing to hash: still publish empty regions
-		HIP_TRY(hipMemsetAsync(send_cnt, 0, (size_t)rp.cnt_bytes_per_shard * n_shards, s));
+		HIP_TRY(hipMemsetAsync(send_cnt, 0, (size_t)rp.cnt_bytes_per_shard * rp.shards_per_window, s));
 		return BTLBF_OK;
 	}
 	ProfSpan ps(f, query ? BTLBF_PROF_QUERY_HASH : BTLBF_PROF_INSERT_HASH, s);

@@ -128,9 +128,19 @@ class HipShardOps:
         return lay
 
     def route_supported(self, global_bits, world):
+        """power-of-two geometry of at least 512 bins x one 64 KiB segment; filters above 2^42 positions are
+        routed in windows of 2^42 and need at least one shard per window (btlbf_route_windows)"""
         pow2 = lambda x: x > 0 and (x & (x - 1)) == 0  # noqa: E731
-        lo = 1 << (26 if self.counting else 29)  # 512 bins of at least one 64 KiB segment
-        return pow2(global_bits) and pow2(world) and lo <= global_bits <= (1 << 42) and 1 <= self.h <= 8
+        if not (pow2(global_bits) and pow2(world) and 1 <= self.h <= 8):
+            return False
+        nw, spw = C.c_uint(), C.c_uint()
+        return self.L.btlbf_route_windows(self.f, world, C.byref(nw), C.byref(spw)) == _lib.OK
+
+    def route_windows(self):
+        """(position windows, shards per window): window w is owned by shards [w * spw, (w + 1) * spw)"""
+        nw, spw = C.c_uint(), C.c_uint()
+        _lib.check(self.L.btlbf_route_windows(self.f, self.world, C.byref(nw), C.byref(spw)))
+        return nw.value, spw.value
 
     def route_plan(self, plan_len, read_len):
         e, c = C.c_uint64(), C.c_uint64()
@@ -138,12 +148,13 @@ class HipShardOps:
         _lib.check(self.L.btlbf_route_plan(self.f, plan_len, C.byref(lay), self.world, C.byref(e), C.byref(c)))
         return e.value, c.value
 
-    def route(self, reads, read_len, plan_len, query, send_ent, send_cnt, hit, valid, counts, spill, spill_count):
+    def route(self, reads, read_len, plan_len, query, send_ent, send_cnt, hit, valid, counts, spill, spill_count,
+              window=0):
         lay = self._lay(read_len)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         _lib.check(self.L.btlbf_route_seqs(self.f, ptr(reads), reads.numel(), C.byref(lay), plan_len, self.world,
-                                           int(query), ptr(send_ent), ptr(send_cnt), ptr(hit), ptr(valid), ptr(counts),
-                                           ptr(spill), spill.numel(), ptr(spill_count), self._sp()))
+                                           int(window), int(query), ptr(send_ent), ptr(send_cnt), ptr(hit), ptr(valid),
+                                           ptr(counts), ptr(spill), spill.numel(), ptr(spill_count), self._sp()))
 
     def apply_routed(self, recv_ent, recv_cnt, n_blocks, plan_len, read_len, query, fail_list, fail_count):
         lay = self._lay(read_len)
@@ -219,12 +230,20 @@ class ShardedBloomFilter:
         # per probe) and applies the probes inside its own window -- W times the hashing, no probe
         # exchange; "exchange": the routed / direct paths below.  auto = gather for 2..4 ranks: xGMI is one
         # link per GPU pair, so the probe exchange is link-bound at small W.
+        # "routed" / "direct" pin the exchange flavour: "routed" raises here when the geometry has no routed
+        # path instead of quietly falling back to the (much slower) direct position exchange
         mode = mode or os.environ.get("BTLBF_SHARD_MODE") or "auto"
-        if mode not in ("auto", "gather", "exchange"):
-            raise ValueError("mode must be auto, gather or exchange")
+        if mode not in ("auto", "gather", "exchange", "routed", "direct"):
+            raise ValueError("mode must be auto, gather, exchange, routed or direct")
         can_gather = hasattr(self.ops, "insert_seqs")
         if mode == "gather" and not can_gather:
             raise ValueError("gather mode: these ops have no whole-buffer insert")
+        if mode == "direct":
+            self.route_enabled = False
+        if mode == "routed" and not self._routed():
+            raise ValueError("routed mode: no routed path for a 2^%.1f-position filter on %d shards with these ops "
+                             "(needs powers of two, at least 2^29 bits, h <= 8)"
+                             % (__import__("math").log2(global_bits), self.world))
         self.mode = "gather" if can_gather and (mode == "gather" or (mode == "auto" and 2 <= self.world <= 4)) \
             else "exchange"
         if self.counting and self.mode != "gather" and not (route and self.ops.route_supported(global_bits, self.world)):
@@ -296,6 +315,13 @@ class ShardedBloomFilter:
     def _bucketed(self, reads, read_len, want_tags):
         n_kmers = (reads.numel() // read_len) * max(read_len - self.k + 1, 0)
         cap = int(n_kmers * self.h / self.world * self.slack) + 4096
+        while reads.numel() == 0:  # a rank that has run out of reads still takes part in the exchange
+            dev = self.ops.device
+            z = torch.zeros(self.world, dtype=torch.int64, device=dev)
+            e = torch.empty(0, dtype=torch.int64, device=dev)
+            recv_cnt = self._exchange_counts(z).cpu().tolist()
+            return e, (e if want_tags else None), [0] * self.world, recv_cnt, \
+                (torch.empty(0, dtype=torch.int64, device=dev) if want_tags else None)
         while True:
             buckets, tags, counts, valid = self.ops.positions(reads, read_len, cap, want_tags)
             cnt = counts.cpu().tolist()  # split sizes must be host integers
@@ -308,9 +334,12 @@ class ShardedBloomFilter:
         return send, stags, cnt, recv_cnt, valid
 
     def _batches(self, reads, read_len):
+        """(offset, chunk) pairs; every rank runs the SAME number of iterations -- each one issues collectives --
+        with empty chunks once its own reads are exhausted"""
         step = self.batch_reads * read_len
-        for off in range(0, reads.numel(), step):
-            yield off, reads[off: off + step]
+        n = self._max_over_ranks(-(-reads.numel() // step))
+        for i in range(n):
+            yield i * step, reads[i * step: (i + 1) * step]
 
     # ---- public -----------------------------------------------------------------------------
     def clear(self):
@@ -352,31 +381,43 @@ class ShardedBloomFilter:
         per = send.numel() // self.world
         return self._rows_all_to_all(recv.view(self.world, per), send.view(self.world, per), async_op)
 
-    def _rows_all_to_all(self, r2, s2, async_op):
-        """row p of s2 goes to rank p, row p of r2 comes from rank p (2-D tensors [world, per] whose rows
-        are contiguous; the rows of s2 may be slices of larger blocks).  At most MSG_BYTES per message;
+    def _rows_all_to_all(self, r2, s2, async_op, first=0, receiving=True):
+        """row i of s2 goes to rank first + i (s2 has one row per TARGET rank: all ranks, or the owners of
+        one position window), row p of r2 comes from rank p when this rank is `receiving` (2-D tensors whose
+        rows are contiguous; the rows of s2 may be slices of larger blocks).  At most MSG_BYTES per message;
         returns the work handles.  With RCCL the row a rank keeps for itself does not go through the
         collective at all: it is one device-to-device copy on the compute stream (BTLBF_FORCE_EXCHANGE=1
         keeps it in, for tests)."""
+        W = self.world
         per = s2.shape[1]
+        n_targets = s2.shape[0]
+        targets = range(first, first + n_targets)
+        everyone = n_targets == W and receiving
         step = max(1, self.MSG_BYTES // s2.element_size())
         local_self = not self.stage_cpu and not self.self_through_rccl
-        if per <= step and not local_self and not self.stage_cpu and s2.is_contiguous() and r2.is_contiguous():
+        if everyone and per <= step and not local_self and not self.stage_cpu and s2.is_contiguous() \
+                and r2.is_contiguous():
             return [dist.all_to_all_single(r2.view(-1), s2.view(-1), group=self.group, async_op=async_op)]
         works = []
         for c0 in range(0, per, step):
             c1 = min(c0 + step, per)
+            n = c1 - c0
             if self.stage_cpu:  # gloo (tests): contiguous copies of the slice through the single-tensor form
-                tmp = torch.empty((self.world, c1 - c0), dtype=s2.dtype)
-                dist.all_to_all_single(tmp, s2[:, c0:c1].contiguous().cpu(), group=self.group)
-                r2[:, c0:c1] = tmp.to(r2.device)
+                ins = [n if p in targets else 0 for p in range(W)]
+                outs = [n if receiving else 0 for _ in range(W)]
+                tmp = torch.empty(sum(outs), dtype=s2.dtype)
+                dist.all_to_all_single(tmp, s2[:, c0:c1].contiguous().cpu().view(-1), output_split_sizes=outs,
+                                       input_split_sizes=ins, group=self.group)
+                if receiving:
+                    r2[:, c0:c1] = tmp.view(W, n).to(r2.device)
             else:
                 keep = (lambda p: p == self.rank) if local_self else (lambda p: False)
-                works.append(dist.all_to_all([r2[p, c0:c0] if keep(p) else r2[p, c0:c1] for p in range(self.world)],
-                                             [s2[p, c0:c0] if keep(p) else s2[p, c0:c1] for p in range(self.world)],
-                                             group=self.group, async_op=async_op))
-        if local_self:
-            r2[self.rank].copy_(s2[self.rank])
+                works.append(dist.all_to_all(
+                    [r2[p, c0:c1] if receiving and not keep(p) else r2[p, c0:c0] for p in range(W)],
+                    [s2[p - first, c0:c1] if p in targets and not keep(p) else s2[0, c0:c0] for p in range(W)],
+                    group=self.group, async_op=async_op))
+        if local_self and receiving and self.rank in targets:
+            r2[self.rank].copy_(s2[self.rank - first])
         return works
 
     def _all_gather_var(self, t, n):
@@ -425,121 +466,157 @@ class ShardedBloomFilter:
         return batch, -(-longest // batch)
 
     def _routed_pass(self, reads, read_len, query, hit_bits=None, counts=None):
-        """One insert / query pass over this rank's reads on the routed path.  Per batch: route (pass A
-        with the global geometry) into a send block set; the owner's bins then travel and are applied a
-        GROUP at a time (1/8 of a shard's level-0 bins: the unit the owner splits and applies anyway), so
-        the receive side needs two groups of buffer instead of two block sets and the exchange of group
-        g+1 overlaps the apply of group g.  With RCCL the next batch is routed on a second stream while
-        the groups of this one are exchanged and applied; nothing in the loop waits on the host.  Spill
-        and fail lists accumulate over the pass and are dealt with once at its end."""
+        """One insert / query pass over this rank's reads on the routed path.  The unit of work is a JOB =
+        (batch of reads, position window): route (pass A with the global geometry, the probes inside the
+        window) into a send block set; the owners' bins then travel and are applied a GROUP at a time (1/8
+        of a shard's level-0 bins: the unit the owner splits and applies anyway), so the receive side needs
+        two groups of buffer instead of two block sets and the exchange of group g+1 overlaps the apply of
+        group g.  Filters of up to 2^42 positions have one window; a 2^43-bit filter on 8 GPUs has two, each
+        owned by 4 consecutive shards, and every batch is routed once per window (only the window's owners
+        receive blocks of that job).  With RCCL the next job is routed on a second stream while the groups
+        of this one are exchanged and applied.  Entries that could not be staged at their origin (skewed
+        input) come back as explicit positions per job; they are collected without limit and exchanged once
+        at the end of the pass, like the fail lists of a query."""
         ops, W, dev = self.ops, self.world, self.ops.device
         exchanging = W > 1 or self.force_exchange
         pipelined = exchanging and (not self.stage_cpu if self.pipeline is None else bool(self.pipeline))
         n_slots = 2 if pipelined else 1
         unit = 64 * read_len
+        n_win, spw = ops.route_windows() if hasattr(ops, "route_windows") else (1, W)
+        my_win = self.rank // spw
         bins, _, _, gb = ops.route_geometry(unit, read_len)  # bins per shard and per group: the same for any length
         G = bins // gb if exchanging else 1
         r_slots = 2 if G > 1 else 1
-        batch, n_batches = self._route_batch_bytes(reads, read_len, n_slots, r_slots / G if exchanging else 0.0)
+        batch, n_batches = self._route_batch_bytes(reads, read_len, n_slots / n_win,
+                                                   r_slots / G if exchanging else 0.0)
         if n_batches == 0:
             return True
+        n_jobs = n_batches * n_win
         ent_b, cnt_b = ops.route_plan(batch, read_len)
         ge, gc = ent_b // G, cnt_b // G  # bytes of one group inside one block
         assert ge * G == ent_b and gc * G == cnt_b and ge % 8 == 0
-        send_ent = [torch.empty(W * ent_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
-        send_cnt = [torch.empty(W * cnt_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
+        send_ent = [torch.empty(spw * ent_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
+        send_cnt = [torch.empty(spw * cnt_b, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
         if exchanging:
             recv_ent = [torch.empty(W * ge, dtype=torch.uint8, device=dev) for _ in range(r_slots)]
             recv_cnt = [torch.empty(W * gc, dtype=torch.uint8, device=dev) for _ in range(r_slots)]
-        spill = torch.empty(self.SPILL_CAP, dtype=torch.int64, device=dev)
-        spill_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        spill = [torch.empty(self.SPILL_CAP, dtype=torch.int64, device=dev) for _ in range(n_slots)]
+        spill_count = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_slots)]
+        spilled = []  # explicit positions of the jobs done so far (device tensors)
         fail = torch.empty(self.FAIL_CAP, dtype=torch.int64, device=dev) if query else None
         fail_count = torch.zeros(1, dtype=torch.int64, device=dev) if query else None
         cnt2 = torch.zeros(2, dtype=torch.int64, device=dev) if query else None
-        # pipelined: routing runs on its own stream, the exchange + apply of the previous batch on the caller's
+        # pipelined: routing runs on its own stream, the exchange + apply of the previous job on the caller's
         cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         side = torch.cuda.Stream(dev) if (pipelined and cur is not None) else None
         routed_ev, free_ev = [None] * n_slots, [None] * n_slots
         if side is not None:
             side.wait_stream(cur)
 
-        def route(bi):
-            slot = bi % n_slots
+        def job_args(j):
+            bi, w = divmod(j, n_win)
             off = bi * batch
             chunk = reads[off: off + batch]  # empty once this rank has run out of reads: it still takes part
             view = None
             if query:
                 w0, nw = off // 64, (chunk.numel() + 63) // 64
                 view = hit_bits[w0: w0 + nw]
+            # every window's pass re-initialises the hit bits of the batch (hit = valid; failures are resolved
+            # at the end of the pass) but the clean windows are counted once
+            return chunk, view, w, (cnt2 if w == 0 else None)
+
+        def do_route(j, slot, again=False):
+            chunk, view, w, c2 = job_args(j)
+            spill_count[slot].zero_()
+            # (a job routed a second time has already counted its clean windows)
+            ops.route(chunk, read_len, batch, query, send_ent[slot], send_cnt[slot], view, None,
+                      None if again else c2, spill[slot], spill_count[slot], window=w)
+
+        def route(j):
+            slot = j % n_slots
             if side is None:
-                ops.route(chunk, read_len, batch, query, send_ent[slot], send_cnt[slot], view, None, cnt2, spill,
-                          spill_count)
+                do_route(j, slot)
                 return
             if free_ev[slot] is not None:
                 side.wait_event(free_ev[slot])  # the exchanges that read this block set have completed
             with torch.cuda.stream(side):
-                ops.route(chunk, read_len, batch, query, send_ent[slot], send_cnt[slot], view, None, cnt2, spill,
-                          spill_count)
+                do_route(j, slot)
                 routed_ev[slot] = torch.cuda.Event()
                 routed_ev[slot].record(side)
 
+        def collect_spill(j, slot):
+            """the job's explicit positions; a list that overflowed (heavily skewed input: poly-A reads, one
+            read a million times) is routed again into one that is large enough -- nothing of the job has
+            left this rank yet"""
+            if routed_ev[slot] is not None:
+                routed_ev[slot].synchronize()
+            n = int(spill_count[slot].item())
+            while n > spill[slot].numel():
+                spill[slot] = torch.empty(n + n // 4 + 1024, dtype=torch.int64, device=dev)
+                do_route(j, slot, again=True)  # on the caller's stream; the blocks come out equivalent
+                n = int(spill_count[slot].item())
+            if n:
+                spilled.append(spill[slot][:n].clone())
+
         def group_rows(t, per_block, g, gbytes):
-            """rows [W, group bytes] of group g inside the W blocks of a send set, as 8-byte elements if possible"""
+            """rows [spw, group bytes] of group g inside the blocks of a send set, as 8-byte elements if possible"""
             if gbytes % 8 == 0 and per_block % 8 == 0:
-                return t.view(torch.int64).view(W, per_block // 8)[:, g * gbytes // 8: (g + 1) * gbytes // 8]
-            return t.view(W, per_block)[:, g * gbytes: (g + 1) * gbytes]
+                return t.view(torch.int64).view(spw, per_block // 8)[:, g * gbytes // 8: (g + 1) * gbytes // 8]
+            return t.view(spw, per_block)[:, g * gbytes: (g + 1) * gbytes]
 
         def flat_rows(t, gbytes):
             return t.view(torch.int64).view(W, gbytes // 8) if gbytes % 8 == 0 else t.view(W, gbytes)
 
-        def exchange(slot, g):
+        def exchange(slot, g, w):
             rs = g % r_slots
             works = []
             for snd, rcv, per_block, gbytes in ((send_ent[slot], recv_ent[rs], ent_b, ge),
                                                 (send_cnt[slot], recv_cnt[rs], cnt_b, gc)):
                 s2 = group_rows(snd, per_block, g, gbytes)
                 r2 = flat_rows(rcv, gbytes) if s2.dtype == torch.int64 else rcv.view(W, gbytes)
-                works += self._rows_all_to_all(r2, s2, async_op=not self.stage_cpu) or []
-            return [w for w in works if w is not None]
+                works += self._rows_all_to_all(r2, s2, async_op=not self.stage_cpu, first=w * spw,
+                                               receiving=(w == my_win)) or []
+            return [x for x in works if x is not None]
 
-        def finish(bi):
-            slot = bi % n_slots
+        def finish(j):
+            slot = j % n_slots
+            w = j % n_win
+            collect_spill(j, slot)
             if side is not None:
                 cur.wait_event(routed_ev[slot])
             if not exchanging:
                 ops.apply_routed(send_ent[slot], send_cnt[slot], W, batch, read_len, query, fail, fail_count)
                 return
-            inflight = {g: exchange(slot, g) for g in range(min(r_slots, G))}
+            inflight = {g: exchange(slot, g, w) for g in range(min(r_slots, G))}
             for g in range(G):
-                for w in inflight.pop(g):
-                    w.wait()  # RCCL: the compute stream waits, the host does not
+                for x in inflight.pop(g):
+                    x.wait()  # RCCL: the compute stream waits, the host does not
                 rs = g % r_slots
-                ops.apply_routed_bins(recv_ent[rs], recv_cnt[rs], W, g * gb, gb, batch, read_len, query, fail,
-                                      fail_count)
+                if w == my_win:
+                    ops.apply_routed_bins(recv_ent[rs], recv_cnt[rs], W, g * gb, gb, batch, read_len, query, fail,
+                                          fail_count)
                 if g + r_slots < G:
-                    inflight[g + r_slots] = exchange(slot, g + r_slots)  # into the buffer just applied
+                    inflight[g + r_slots] = exchange(slot, g + r_slots, w)  # into the buffer just applied
             if side is not None:
                 free_ev[slot] = torch.cuda.Event()
                 free_ev[slot].record(cur)
 
         pending = None
-        for bi in range(n_batches):
-            route(bi)
+        for j in range(n_jobs):
+            route(j)
             if pipelined:
                 if pending is not None:
                     finish(pending)
-                pending = bi
+                pending = j
             else:
-                finish(bi)
+                finish(j)
         if pending is not None:
             finish(pending)
         if side is not None:
             cur.wait_stream(side)
         # entries that could not be staged at their origin travel as explicit positions (rare)
-        n_spill = int(spill_count.item())
-        if self._max_over_ranks(1 if n_spill > self.SPILL_CAP else 0):
-            return False
-        gathered = self._all_gather_var(spill, n_spill)
+        mine = torch.cat(spilled) if spilled else torch.empty(0, dtype=torch.int64, device=dev)
+        gathered = self._all_gather_var(mine, mine.numel())
         if gathered.numel():
             ops.apply_spill(gathered, query, fail, fail_count)
         if query:
@@ -685,8 +762,7 @@ class ShardedBloomFilter:
         if self.mode == "gather":
             return self._gather_pass(reads, read_len, 0)
         if self._routed():
-            if not self._routed_pass(reads, read_len, 0):
-                raise RuntimeError("routed insert: spill list overflow")
+            self._routed_pass(reads, read_len, 0)
             return
         if self.counting:
             raise RuntimeError("counting filters have no direct exchange path")

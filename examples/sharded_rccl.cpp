@@ -100,7 +100,8 @@ int main(int argc, char** argv)
 			CHECK_HIP(hipMemsetAsync(r[g].spill_count, 0, 8, r[g].s));
 			CHECK_HIP(hipMemsetAsync(r[g].fail_count, 0, 8, r[g].s));
 			CHECK_HIP(hipMemsetAsync(r[g].counts, 0, 16, r[g].s));
-			CHECK_BF(btlbf_route_seqs(r[g].f, r[g].reads, len, &lay, len, W, query, r[g].send_ent, r[g].send_cnt,
+			// window 0: this example handles filters of up to 2^42 bits (one position window, btlbf_route_windows)
+			CHECK_BF(btlbf_route_seqs(r[g].f, r[g].reads, len, &lay, len, W, 0, query, r[g].send_ent, r[g].send_cnt,
 			                          query ? r[g].hit : nullptr, nullptr, query ? r[g].counts : nullptr, r[g].spill,
 			                          spill_cap, r[g].spill_count, r[g].s));
 		}

@@ -250,15 +250,20 @@ int btlbf_test_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n,
 int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, unsigned hash_num,
                       uint64_t* hit_bits, int device, void* stream);
 /* ---- multi-GPU on the partitioned pipeline (large batches) -----------------------
- * Needs a bit filter whose GLOBAL size and shard count are powers of two (2^29..2^42 bits).  The global
- * position space is cut into B level-0 bins (512, or 1024 above 2^41 bits); shard g owns bins
- * [g*B/n, (g+1)*B/n).  All
- * pointers are device pointers.
+ * Needs a filter whose GLOBAL size and shard count are powers of two (at least 2^29 bits / 2^26 counters).
+ * An entry is the 32-bit offset of a position inside its level-0 bin and an origin stages at most 1024 bins,
+ * so one routing pass covers a WINDOW of at most 2^42 positions: a larger filter (BASELINE config 4: 2^43
+ * bits on 8 GPUs) has several windows, each owned by n_shards / n_windows consecutive shards, and the same
+ * reads are routed once per window (btlbf_route_windows; position semantics BloomFilter.hpp:190).  A window
+ * is cut into B level-0 bins (512, or 1024 when a window has more than 2^41 positions); the s-th shard of
+ * a window owns its bins [s*B/spw, (s+1)*B/spw).  All pointers are device pointers.
+ *  route_windows: how many windows this geometry has, and how many shards own each.
  *  route_plan : byte sizes of ONE origin->owner block for a buffer of `plan_len` bytes.  Every rank
  *               must plan with the same plan_len (e.g. the maximum over ranks) so that blocks have one
  *               size and the exchange is a fixed-size all-to-all.
- *  route_seqs : origin.  Hash the buffer and partition every probe position into the 1024 bins:
- *               send_ent / send_cnt receive n_shards consecutive blocks (block g goes to shard g).
+ *  route_seqs : origin.  Hash the buffer and partition every probe position inside `window` into the window's
+ *               bins: send_ent / send_cnt receive shards_per_window consecutive blocks (block i goes to shard
+ *               window*shards_per_window + i).
  *               query != 0 additionally writes valid_bits and initialises hit_bits = valid_bits;
  *               counts[0] (optional) += clean windows.  Entries that cannot be staged are appended to
  *               spill_list as global positions.  counts and spill_count ACCUMULATE over calls (zero
@@ -282,10 +287,11 @@ int btlbf_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, 
  *               global positions. */
 int btlbf_route_plan(btlbf_filter* f, uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards,
                      uint64_t* ent_bytes_per_shard, uint64_t* cnt_bytes_per_shard);
+int btlbf_route_windows(btlbf_filter* f, unsigned n_shards, unsigned* n_windows, unsigned* shards_per_window);
 int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
-                     uint64_t plan_len, unsigned n_shards, int query, void* send_ent, void* send_cnt,
-                     uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts, uint64_t* spill_list,
-                     uint64_t spill_cap, uint64_t* spill_count, void* stream);
+                     uint64_t plan_len, unsigned n_shards, unsigned window, int query, void* send_ent,
+                     void* send_cnt, uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts,
+                     uint64_t* spill_list, uint64_t spill_cap, uint64_t* spill_count, void* stream);
 int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
                        uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards, int query,
                        uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream);

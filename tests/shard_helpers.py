@@ -106,9 +106,10 @@ def _init(rank, world, port, backend="gloo"):
     dist.init_process_group(backend, rank=rank, world_size=world)
 
 
-def cpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len, mode="exchange"):
+def cpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len, mode="exchange", uneven=0):
     """gloo + oracle stand-in: validates bucketing / all-to-all / answer routing (mode="gather": the
-    read gather, the window-partial answers and their AND at the reads' owner)"""
+    read gather, the window-partial answers and their AND at the reads' owner).  uneven: rank r holds
+    n_reads - r * uneven reads, so the ranks run out of batches at different times"""
     from oracle.pyoracle import Oracle
 
     from btl_bloomfilter_amd.sharded import ShardedBloomFilter
@@ -120,13 +121,14 @@ def cpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len, mode="e
                            batch_bytes_cap=(64 * read_len if mode == "gather" else 0))
     if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
         f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
-    mine = torch.from_numpy(o.synth_reads(42, rank * n_reads, n_reads, read_len))
+    n_mine = n_reads - rank * uneven
+    mine = torch.from_numpy(o.synth_reads(42, rank * n_reads, n_mine, read_len))
     f.insert_reads(mine, read_len)
     dist.barrier()
     np.save(os.path.join(outdir, "body%d.npy" % rank), ops.local_body())
     # query: own reads (hits) followed by reads nobody inserted
-    q = torch.from_numpy(np.concatenate([o.synth_reads(42, rank * n_reads, n_reads, read_len),
-                                         o.synth_reads(43, rank * n_reads, n_reads, read_len)]))
+    q = torch.from_numpy(np.concatenate([o.synth_reads(42, rank * n_reads, n_mine, read_len),
+                                         o.synth_reads(43, rank * n_reads, n_mine, read_len)]))
     hit = torch.zeros((q.numel() + 63) // 64, dtype=torch.int64)
     cnt = torch.zeros(2, dtype=torch.int64)
     f.contains_reads(q, read_len, hit, cnt)
@@ -164,11 +166,15 @@ def gpu_worker(rank, world, port, outdir, bits, h, k, n_reads, read_len):
 
 
 def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, route_bins=0, pipeline=None,
-                      mode="exchange"):
+                      mode="exchange", window_bits=0, spill_cap=0, skew=0):
     """the routed (partitioned) multi-GPU path -- or, mode="gather", the gather path -- with the real HIP
-    kernels, all ranks on cuda:0"""
+    kernels, all ranks on cuda:0.  window_bits: BTLBF_ROUTE_WINDOW_BITS (several position windows on a
+    small filter); spill_cap: size of the per-job spill lists; skew: copies of one read appended to every
+    rank's reads (hot positions that cannot be staged at the origin)"""
     if route_bins:
         os.environ["BTLBF_ROUTE_BINS"] = str(route_bins)
+    if window_bits:
+        os.environ["BTLBF_ROUTE_WINDOW_BITS"] = str(window_bits)
     import btl_bloomfilter_amd as m
     from btl_bloomfilter_amd.sharded import ShardedBloomFilter
 
@@ -179,7 +185,14 @@ def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, 
     if os.environ.get("BTLBF_TEST_MSG_BYTES"):  # force the sliced exchange (messages above this size)
         f.MSG_BYTES = int(os.environ["BTLBF_TEST_MSG_BYTES"])
     assert f.mode == mode and (mode == "gather" or f._routed())
+    if spill_cap:
+        f.SPILL_CAP = spill_cap
+    if window_bits:
+        assert f.ops.route_windows()[0] == bits >> window_bits
     mine = m.synth_reads_device(42, rank * n_reads, n_reads, read_len)
+    hot = m.synth_reads_device(45, 0, 1, read_len).repeat(skew) if skew else None
+    if skew:
+        mine = torch.cat([mine, hot])
     f.insert_reads(mine, read_len)
     torch.cuda.synchronize()
     dist.barrier()
@@ -189,6 +202,8 @@ def gpu_worker_routed(rank, world, port, outdir, bits, h, k, n_reads, read_len, 
     ref.setInsertMode("direct")
     ref.setQueryMode("direct")
     ref.insertSeqs(m.synth_reads_device(42, 0, world * n_reads, read_len), read_len=read_len)
+    if skew:
+        ref.insertSeqs(hot[:read_len], read_len=read_len)
     res = {}
     mine_body = f.ops.local_body()
     whole = ref.download()

@@ -53,6 +53,30 @@ def test_sharded_routing_gloo_cpu(oracle, tmp_path, msg_bytes, monkeypatch):
     check_queries(oracle, body, bits, h, k, world, n_reads, L, str(tmp_path))
 
 
+@pytest.mark.parametrize("mode", ["exchange", "gather"])
+def test_sharded_uneven_read_counts_gloo_cpu(oracle, tmp_path, mode):
+    """ranks that hold different numbers of reads (rank 1 runs out of batches first) must still take part
+    in every collective: world 3, the direct position exchange and the gather path"""
+    bits, h, k, world, n_reads, L, uneven = 3 << 14, 3, 25, 3, 150, 150, 60
+    mp.spawn(cpu_worker, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L, mode, uneven), nprocs=world,
+             join=True)
+    body = np.zeros(bits // 8, np.uint8)
+    for rank in range(world):
+        for r in oracle.synth_reads(42, rank * n_reads, n_reads - rank * uneven, L).reshape(-1, L):
+            oracle.bf_insert_seq(body, bits, h, k, r.tobytes())
+    got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+    assert (got == body).all()
+    for rank in range(world):
+        n = n_reads - rank * uneven
+        q = np.concatenate([oracle.synth_reads(42, rank * n_reads, n, L), oracle.synth_reads(43, rank * n_reads, n, L)])
+        eh = []
+        for r in q.reshape(-1, L):
+            a, _ = oracle.bf_contains_seq_dense(body, bits, h, k, r.tobytes())
+            eh.append(np.concatenate([a, np.zeros(k - 1, np.uint8)]))
+        hit = np.unpackbits(np.load(tmp_path / ("hit%d.npy" % rank)).view(np.uint8), bitorder="little")[: q.size]
+        assert (hit == np.concatenate(eh)).all(), rank
+
+
 @pytest.mark.parametrize("world,bits", [(2, 1 << 16), (3, 3 << 14)])
 def test_sharded_gather_mode_gloo_cpu(oracle, tmp_path, world, bits):
     """gather mode over gloo with the oracle stand-in: several rounds of the read gather (the last one
@@ -201,6 +225,55 @@ def test_sharded_routed_two_split_levels_and_32bit_entries(tmp_path):
     body = ref.download()
     got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
     assert (got == body).all()
+
+
+@pytest.mark.gpu
+def test_sharded_routed_position_windows_c4_geometry(tmp_path):
+    """BASELINE config 4 (2^43 bits on 8 GPUs) has TWO position windows of 2^42 bits, each owned by four
+    shards, 32-bit entries and two split passes at the owner.  Reproduced on one GPU with 4 ranks: 2^37
+    bits, windows of 2^36 (BTLBF_ROUTE_WINDOW_BITS) with 16 level-0 bins each (2^32 positions per bin).
+    Shard bodies against a single filter built by the direct kernel; all-hit, few-miss and miss-heavy
+    queries against the direct kernel."""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 << 30:
+        pytest.skip("needs ~100 GiB of HBM (4 shards + 4 whole reference filters of 16 GiB)")
+    bits, h, k, L, world, n_reads = 1 << 37, 4, 31, 150, 4, 60000
+    mp.spawn(gpu_worker_routed, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L, 16, None, "exchange", 36),
+             nprocs=world, join=True)
+    for rank in range(world):
+        res = eval(str(np.load(tmp_path / ("res%d.npy" % rank))[0]))
+        for name, (same, cnt, exp) in res.items():
+            assert same, (rank, name)
+            assert cnt == exp, (rank, name, cnt, exp)
+        assert res["hits"][1][0] == res["hits"][1][1] == n_reads * (L - k + 1)
+
+
+@pytest.mark.gpu
+def test_sharded_routed_skewed_reads_overflow_the_spill_lists(tmp_path):
+    """20 000 copies of one read per rank: their probes cannot be staged at the origin and come back as
+    explicit positions, far more than a spill list of 4096 holds -- the job is routed again into a larger
+    list, nothing is lost and nothing raises (bit filter: the body equals the direct kernel's)"""
+    bits, h, k, L, world, n_reads = 1 << 30, 4, 31, 150, 2, 20000
+    mp.spawn(gpu_worker_routed, args=(world, free_port(), str(tmp_path), bits, h, k, n_reads, L, 0, None, "exchange", 0,
+                                      4096, 20000), nprocs=world, join=True)
+    for rank in range(world):
+        res = eval(str(np.load(tmp_path / ("res%d.npy" % rank))[0]))
+        for name, (same, cnt, exp) in res.items():
+            assert same, (rank, name)
+            assert cnt == exp, (rank, name, cnt, exp)
+
+
+def test_sharded_routed_mode_is_never_silently_replaced(oracle):
+    """mode="routed" with ops (or a geometry) that have no routed path raises instead of falling back to the
+    direct position exchange"""
+    from shard_helpers import OracleShardOps
+
+    from btl_bloomfilter_amd.sharded import ShardedBloomFilter
+
+    with pytest.raises(ValueError, match="routed"):
+        ShardedBloomFilter(1 << 16, 4, 31, ops=OracleShardOps(1 << 16, 4, 31, 0, 1), mode="routed")
 
 
 @pytest.mark.gpu
