@@ -82,9 +82,21 @@ def host_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n_reads, log2_bits):
-    """Reference CPU path (ntHashIterator + BloomFilter insert/contains, OpenMP over reads) on a
-    bounded sample; falls back to the C port when the reference build is not on this machine."""
+    """Reference CPU path (ntHashIterator + BloomFilter insert/contains, OpenMP over reads) on bounded samples
+    of the bench workload: all host cores and one thread, plus the C port next to the genuine
+    reference on BASELINE config 1's filter (2^33 bits) so that a "port" number can be read as a reference
+    number.  Falls back to the C port alone when the reference build is not on this machine."""
     from oracle import pyoracle
 
     cores = host_cores()
@@ -93,24 +105,47 @@ def cpu_baseline(n_reads, log2_bits):
     while lg > 30 and (1 << lg) // 8 > 0.55 * avail:
         lg -= 1
     bits = 1 << lg
+    pyoracle.build()
+    port = pyoracle.Oracle()
     if pyoracle.Ref.available():
         kind, runner = "reference", pyoracle.Ref()
     else:
-        pyoracle.build()
-        kind, runner = "port", pyoracle.Oracle()
+        kind, runner = "port", port
+
+    def rate(r):
+        return {"Mkmers_s": 2 * r["kmers"] / (r["t_insert"] + r["t_query"]) / 1e6,
+                "insert_Mkmers_s": r["kmers"] / r["t_insert"] / 1e6, "query_Mkmers_s": r["kmers"] / r["t_query"] / 1e6,
+                "threads": r["threads"], "kmers": r["kmers"], "query_hits": r["hits"]}
+
     t0 = time.time()
-    r = runner.bench_bf(n_reads, READ_LEN, K, H, bits, 42, 42, threads=cores, prefault=1)
+    allc = runner.bench_bf(n_reads, READ_LEN, K, H, bits, 42, 42, threads=cores, prefault=1)
+    n1 = max(n_reads // 16, 50_000)
+    one = runner.bench_bf(n1, READ_LEN, K, H, bits, 42, 42, threads=1, prefault=0)  # pages already touched
     wall = time.time() - t0
-    kmers = r["kmers"]
-    val = 2 * kmers / (r["t_insert"] + r["t_query"]) / 1e6
-    return {
-        "value": val, "unit": "Mk-mers/s", "cores": r["threads"], "kind": kind,
-        "insert_Mkmers_s": kmers / r["t_insert"] / 1e6, "query_Mkmers_s": kmers / r["t_query"] / 1e6,
-        "sample": "%d synthetic 150 bp reads (seed 42) inserted then queried (all hits), k=31 h=4, "
-                  "2^%d-bit filter (%s), pages pre-touched, OpenMP over reads, %.0f s wall incl. prefault"
-                  % (n_reads, lg, "same size as the GPU run" if lg == log2_bits else "scaled to host RAM", wall),
-        "query_hits": r["hits"], "kmers": kmers,
+    out = {
+        "value": rate(allc)["Mkmers_s"], "unit": "Mk-mers/s", "cores": allc["threads"], "kind": kind,
+        "cpu_model": cpu_model(),
+        "insert_Mkmers_s": rate(allc)["insert_Mkmers_s"], "query_Mkmers_s": rate(allc)["query_Mkmers_s"],
+        "one_thread": dict(rate(one), reads=n1),
+        "sample": "%d synthetic 150 bp reads (seed 42) inserted then queried (all hits), k=31 h=4, 2^%d-bit filter "
+                  "(%s), pages pre-touched, OpenMP over reads, all %d cores; then %d reads on one thread; %.0f s wall "
+                  "incl. prefault" % (n_reads, lg, "same size as the GPU run" if lg == log2_bits else "scaled to host RAM",
+                                      allc["threads"], n1, wall),
+        "query_hits": allc["hits"], "kmers": allc["kmers"],
     }
+    # calibration of the port against the genuine reference (same machine, same sample, C1's 2^33-bit filter)
+    if kind == "reference":
+        try:
+            nc = max(n_reads // 4, 100_000)
+            r_ref = runner.bench_bf(nc, READ_LEN, K, H, 1 << 33, 42, 42, threads=cores, prefault=1)
+            r_port = port.bench_bf(nc, READ_LEN, K, H, 1 << 33, 42, 42, threads=cores, prefault=1)
+            out["port_vs_reference_c1"] = {
+                "reads": nc, "log2_bits": 33, "threads": r_ref["threads"],
+                "reference_Mkmers_s": rate(r_ref)["Mkmers_s"], "port_Mkmers_s": rate(r_port)["Mkmers_s"],
+                "ratio_port_over_reference": rate(r_port)["Mkmers_s"] / rate(r_ref)["Mkmers_s"]}
+        except Exception as exc:  # never lose the baseline over its calibration
+            out["port_vs_reference_c1"] = {"error": repr(exc)}
+    return out
 
 
 # algorithmic HBM bytes one launch of each kernel moves: per k-mer figures with
@@ -207,6 +242,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
+    # N = 8 runs BASELINE config 4 itself: a 2^43-bit (1 TiB) filter hash-sharded over the 8 GPUs (128 GiB
+    # shards, two position windows on the routed path) and 10^9 reads = 1.25e8 per GPU -- unless the caller
+    # set sizes explicitly
+    c4 = world == 8 and args.reads == N_READS and args.log2_bits == LOG2_BITS
+    if c4:
+        args.reads, args.log2_bits = 125_000_000, 40
     n_reads = args.reads
     bits_per_gpu = 1 << args.log2_bits
     kmers = n_reads * (READ_LEN - K + 1)
@@ -245,7 +286,9 @@ def main():
     else:
         from btl_bloomfilter_amd.sharded import ShardedBloomFilter
 
-        flt = ShardedBloomFilter(bits_per_gpu * world, H, K, device=local_rank)
+        # 8 ranks: the routed path, and never a silent fall-back to the direct position exchange
+        flt = ShardedBloomFilter(bits_per_gpu * world, H, K, device=local_rank,
+                                 mode=os.environ.get("BTLBF_SHARD_MODE") or ("routed" if world >= 8 else None))
 
         def do_insert():
             flt.insert_reads(reads, READ_LEN)
@@ -311,9 +354,14 @@ def main():
             "value": value, "unit": "Mk-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: per GPU 2^%d-bit BloomFilter, k=31, h=4, %d synthetic 150 bp reads "
-                                   "inserted then queried (all hits), reads resident in HBM"
-                                   % (args.log2_bits, n_reads),
+            "config": {"workload": ("C4: 2^43-bit (1 TiB) BloomFilter hash-sharded over 8 GPUs (2^40-bit shards), k=31, "
+                                    "h=4, 10^9 synthetic 150 bp reads (%d per GPU) inserted then queried (all hits), "
+                                    "reads resident in HBM" % n_reads) if c4 else
+                                   ("C2: per GPU 2^%d-bit BloomFilter, k=31, h=4, %d synthetic 150 bp reads "
+                                    "inserted then queried (all hits), reads resident in HBM"
+                                    % (args.log2_bits, n_reads)),
+                       "collective_world_size": (dist.get_world_size() if dist is not None else 1),
+                       "collective_backend": (dist.get_backend() if dist is not None else "none"),
                        "filter_bits_total": bits_per_gpu * world, "kmers_per_pass": total_kmers,
                        "parallelism": "1 GPU" if single else
                                       ("hash-range shards x%d, reads all-gathered over RCCL, every shard hashes all "
@@ -343,6 +391,9 @@ def main():
             d = kernels[dom]
             out["roofline"] = {"kernel": d["kernel"], "bound": "hbm", "achieved": d["achieved"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": d["frac"], "traffic": d["traffic"],
+                               "traffic_source": (traffic.get("source", "profiles/traffic.json") + " -- read from the "
+                                                  "committed PMC summary, NOT measured in this run")
+                               if d["traffic"] is not None else None,
                                "bytes_per_launch": d["bytes_per_launch"], "kmers_per_launch": d["kmers_per_launch"],
                                "launch_ms": d["avg_launch_ms"], "share_of_timed_region": d["share_of_timed_region"],
                                "note": "dominant kernel by HIP-event time; its algorithmic bytes are the streamed "

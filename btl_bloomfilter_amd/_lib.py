@@ -5,7 +5,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbtlbf.so")
+# BTLBF_LIB selects another build of the SAME library (diagnostic / sanitizer builds made by build.py with
+# BTLBF_BUILD_TAG, tools/sanitize_host.sh); there is no other implementation to select
+LIB_PATH = os.environ.get("BTLBF_LIB") or os.path.join(HERE, "libbtlbf.so")
 
 HOST, DEVICE = 0, 1
 BLOOM, COUNTING8 = 0, 1

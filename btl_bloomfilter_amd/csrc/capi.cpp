@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <mutex>
 #include <string>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -67,6 +68,10 @@ extern "C" int btlbf_device_count(void)
 // filter object
 // -------------------------------------------------------------------------------------------------
 struct btlbf_filter {
+	// every entry point that takes the filter holds this for its whole duration: a filter keeps device
+	// scratch, event lists and a scalar buffer between calls, so concurrent callers are serialised here
+	// (recursive: btlbf_store -> btlbf_store_shard, btlbf_apply_routed -> btlbf_apply_routed_bins)
+	mutable std::recursive_mutex mu;
 	int kind = BTLBF_BLOOM;
 	int device = 0;
 	uint64_t size = 0;        // global bits / counters
@@ -104,6 +109,23 @@ struct btlbf_filter {
 };
 
 namespace {
+
+struct FilterLock {
+	const btlbf_filter* f;
+	explicit FilterLock(const btlbf_filter* f_)
+	  : f(f_)
+	{
+		if (f)
+			f->mu.lock();
+	}
+	~FilterLock()
+	{
+		if (f)
+			f->mu.unlock();
+	}
+	FilterLock(const FilterLock&) = delete;
+	FilterLock& operator=(const FilterLock&) = delete;
+};
 
 // times one kernel launch with a pair of events when profiling is on
 struct ProfSpan {
@@ -578,6 +600,7 @@ extern "C" int btlbf_destroy(btlbf_filter* f)
 
 extern "C" int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch_bytes)
 {
+	FilterLock lk__(f);
 	if (!f || mode < BTLBF_INSERT_AUTO || mode > BTLBF_INSERT_PARTITIONED)
 		return fail(BTLBF_EINVAL, "bad insert mode");
 	f->insert_mode = mode;
@@ -587,6 +610,7 @@ extern "C" int btlbf_set_insert_mode(btlbf_filter* f, int mode, uint64_t scratch
 
 extern "C" int btlbf_release_scratch(btlbf_filter* f)
 {
+	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
 	DeviceGuard g(f->device);
@@ -598,6 +622,7 @@ extern "C" int btlbf_release_scratch(btlbf_filter* f)
 
 extern "C" int btlbf_set_profiling(btlbf_filter* f, int on)
 {
+	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
 	f->profiling = on != 0;
@@ -606,6 +631,7 @@ extern "C" int btlbf_set_profiling(btlbf_filter* f, int on)
 
 extern "C" int btlbf_get_profile(btlbf_filter* f, double* ms, unsigned* calls, int reset)
 {
+	FilterLock lk__(f);
 	if (!f || !ms || !calls)
 		return fail(BTLBF_EINVAL, "null argument");
 	DeviceGuard g(f->device);
@@ -632,6 +658,7 @@ extern "C" int btlbf_get_profile(btlbf_filter* f, double* ms, unsigned* calls, i
 
 extern "C" int btlbf_set_query_mode(btlbf_filter* f, int mode)
 {
+	FilterLock lk__(f);
 	if (!f || mode < BTLBF_INSERT_AUTO || mode > BTLBF_INSERT_PARTITIONED)
 		return fail(BTLBF_EINVAL, "bad query mode");
 	f->query_mode = mode;
@@ -641,6 +668,7 @@ extern "C" int btlbf_set_query_mode(btlbf_filter* f, int mode)
 extern "C" int btlbf_set_spaced_seeds(btlbf_filter* f, const char* const* seeds, unsigned n_seeds,
                                       unsigned h2)
 {
+	FilterLock lk__(f);
 	if (!f || !seeds)
 		return fail(BTLBF_EINVAL, "null argument");
 	if (n_seeds * h2 != f->h)
@@ -683,6 +711,7 @@ extern "C" int btlbf_device(const btlbf_filter* f) { return f->device; }
 
 extern "C" int btlbf_clear(btlbf_filter* f, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
 	DeviceGuard g(f->device);
@@ -692,6 +721,7 @@ extern "C" int btlbf_clear(btlbf_filter* f, void* stream)
 
 extern "C" int btlbf_upload(btlbf_filter* f, const void* src, uint64_t offset, uint64_t nbytes)
 {
+	FilterLock lk__(f);
 	if (!f || (!src && nbytes))
 		return fail(BTLBF_EINVAL, "null argument");
 	if (offset + nbytes > f->local_bytes)
@@ -704,6 +734,7 @@ extern "C" int btlbf_upload(btlbf_filter* f, const void* src, uint64_t offset, u
 
 extern "C" int btlbf_download(const btlbf_filter* f, void* dst, uint64_t offset, uint64_t nbytes)
 {
+	FilterLock lk__(f);
 	if (!f || (!dst && nbytes))
 		return fail(BTLBF_EINVAL, "null argument");
 	if (offset + nbytes > f->local_bytes)
@@ -719,6 +750,7 @@ extern "C" int btlbf_download(const btlbf_filter* f, void* dst, uint64_t offset,
 // -------------------------------------------------------------------------------------------------
 extern "C" int btlbf_header(const btlbf_filter* f, char* buf, size_t cap, size_t* len)
 {
+	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
 	const std::string h = header_text(f);
@@ -833,6 +865,7 @@ static int write_body(const btlbf_filter* f, int fd, uint64_t file_off, const ch
 
 extern "C" int btlbf_store_shard(btlbf_filter* f, const char* path)
 {
+	FilterLock lk__(f);
 	if (!f || !path)
 		return fail(BTLBF_EINVAL, "null argument");
 	DeviceGuard g(f->device);
@@ -858,6 +891,7 @@ extern "C" int btlbf_store_shard(btlbf_filter* f, const char* path)
 
 extern "C" int btlbf_store(btlbf_filter* f, const char* path)
 {
+	FilterLock lk__(f);
 	if (f && f->shard_count != 1)
 		return fail(BTLBF_EINVAL, "btlbf_store on a shard: use btlbf_store_shard");
 	return btlbf_store_shard(f, path);
@@ -1519,6 +1553,7 @@ int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, uns
 extern "C" int btlbf_route_plan(btlbf_filter* f, uint64_t len, const btlbf_layout* layout, unsigned n_shards,
                                 uint64_t* ent_bytes_per_shard, uint64_t* cnt_bytes_per_shard)
 {
+	FilterLock lk__(f);
 	if (!f || !ent_bytes_per_shard || !cnt_bytes_per_shard)
 		return fail(BTLBF_EINVAL, "null argument");
 	LayoutParams lay{nullptr, 0, 0};
@@ -1539,6 +1574,7 @@ extern "C" int btlbf_route_plan(btlbf_filter* f, uint64_t len, const btlbf_layou
 extern "C" int btlbf_route_windows(btlbf_filter* f, unsigned n_shards, unsigned* n_windows,
                                    unsigned* shards_per_window)
 {
+	FilterLock lk__(f);
 	if (!f || !n_windows || !shards_per_window)
 		return fail(BTLBF_EINVAL, "null argument");
 	RoutePlan rp;
@@ -1555,6 +1591,7 @@ extern "C" int btlbf_route_seqs(btlbf_filter* f, const char* seq, uint64_t len, 
                                 void* send_cnt, uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts,
                                 uint64_t* spill_list, uint64_t spill_cap, uint64_t* spill_count, void* stream)
 {
+	FilterLock lk__(f);
 	int rc = seq_precheck(f, len);
 	if (rc)
 		return rc;
@@ -1632,6 +1669,7 @@ LayoutParams layout_params(const btlbf_layout* layout)
 extern "C" int btlbf_route_geometry(btlbf_filter* f, uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards,
                                     unsigned n_blocks, uint32_t* out4)
 {
+	FilterLock lk__(f);
 	if (!f || !out4)
 		return fail(BTLBF_EINVAL, "null argument");
 	const LayoutParams lay = layout_params(layout);
@@ -1654,6 +1692,7 @@ extern "C" int btlbf_apply_routed_bins(btlbf_filter* f, const void* recv_ent, co
                                        const btlbf_layout* layout, unsigned n_shards, int query, uint64_t* fail_list,
                                        uint64_t fail_cap, uint64_t* fail_count, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f || !recv_ent || !recv_cnt || n_blocks == 0)
 		return fail(BTLBF_EINVAL, "null argument");
 	if (f->shard_count != n_shards)
@@ -1697,6 +1736,7 @@ extern "C" int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const v
                                   uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards, int query,
                                   uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null argument");
 	const LayoutParams lay = layout_params(layout);
@@ -1711,6 +1751,7 @@ extern "C" int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const v
 extern "C" int btlbf_apply_spill(btlbf_filter* f, const uint64_t* global_pos, uint64_t n, int query,
                                  uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f || (n && !global_pos))
 		return fail(BTLBF_EINVAL, "null argument");
 	DeviceGuard g(f->device);
@@ -1729,6 +1770,7 @@ extern "C" int btlbf_apply_spill(btlbf_filter* f, const uint64_t* global_pos, ui
 extern "C" int btlbf_resolve_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
                                   const uint64_t* fail_list, uint64_t n_fail, uint64_t* hit_bits, void* stream)
 {
+	FilterLock lk__(f);
 	int rc = seq_precheck(f, len);
 	if (rc)
 		return rc;
@@ -1760,6 +1802,7 @@ namespace {
 extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
                                  const btlbf_layout* layout, int op, int order, int mem, void* stream)
 {
+	FilterLock lk__(f);
 	int rc = seq_precheck(f, len);
 	if (rc)
 		return rc;
@@ -1831,6 +1874,7 @@ extern "C" int btlbf_contains_seqs(btlbf_filter* f, const char* seq, uint64_t le
                                    const btlbf_layout* layout, uint64_t* hit_bits, uint64_t* valid_bits,
                                    uint64_t* counts, int mem, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
 	return run_query_like(f, f->kind == BTLBF_BLOOM ? OP_BF_CONTAINS : OP_CBF_QUERY, seq, len, layout,
@@ -1841,6 +1885,7 @@ extern "C" int btlbf_insert_and_check_seqs(btlbf_filter* f, const char* seq, uin
                                            const btlbf_layout* layout, uint64_t* hit_bits,
                                            uint64_t* valid_bits, uint64_t* counts, int mem, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
 	if (f->kind != BTLBF_BLOOM)
@@ -1853,6 +1898,7 @@ extern "C" int btlbf_min_count_seqs(btlbf_filter* f, const char* seq, uint64_t l
                                     const btlbf_layout* layout, uint8_t* min_out, uint64_t* valid_bits,
                                     int mem, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
 	if (f->kind != BTLBF_COUNTING8)
@@ -1901,6 +1947,7 @@ int run_hash_rows(btlbf_filter* f, int hop, const uint64_t* hashes, uint64_t n, 
 extern "C" int btlbf_insert_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, int op, int order,
                                    int mem, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
 	int hop = H_BF_INSERT;
@@ -1916,6 +1963,7 @@ extern "C" int btlbf_insert_hashes(btlbf_filter* f, const uint64_t* hashes, uint
 extern "C" int btlbf_contains_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, uint8_t* out,
                                      int mem, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f || !out)
 		return fail(BTLBF_EINVAL, "null argument");
 	return run_hash_rows(f, f->kind == BTLBF_BLOOM ? H_BF_CONTAINS : H_CBF_CONTAINS, hashes, n, out, 0, mem,
@@ -1925,6 +1973,7 @@ extern "C" int btlbf_contains_hashes(btlbf_filter* f, const uint64_t* hashes, ui
 extern "C" int btlbf_insert_and_check_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n,
                                              uint8_t* out, int order, int mem, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f || !out)
 		return fail(BTLBF_EINVAL, "null argument");
 	return run_hash_rows(f, f->kind == BTLBF_BLOOM ? H_BF_INSERT_CHECK : H_CBF_INSERT_CHECK, hashes, n, out,
@@ -1934,6 +1983,7 @@ extern "C" int btlbf_insert_and_check_hashes(btlbf_filter* f, const uint64_t* ha
 extern "C" int btlbf_min_count_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, uint8_t* min_out,
                                       int mem, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f || !min_out)
 		return fail(BTLBF_EINVAL, "null argument");
 	if (f->kind != BTLBF_COUNTING8)
@@ -2023,11 +2073,13 @@ static int popcount_mode(btlbf_filter* f, int mode, uint64_t* out)
 
 extern "C" int btlbf_popcount(btlbf_filter* f, uint64_t* out)
 {
+	FilterLock lk__(f);
 	return popcount_mode(f, f && f->kind == BTLBF_COUNTING8 ? 1 : 0, out);
 }
 
 extern "C" int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out)
 {
+	FilterLock lk__(f);
 	if (f && f->kind != BTLBF_COUNTING8)
 		return fail(BTLBF_EINVAL, "filtered_popcount needs a counting filter");
 	return popcount_mode(f, 2, out);
@@ -2037,6 +2089,7 @@ extern "C" int btlbf_compare(btlbf_filter* a, btlbf_filter* b, uint64_t* out3)
 {
 	if (!a || !b || !out3)
 		return fail(BTLBF_EINVAL, "null argument");
+	FilterLock lk1__(a < b ? a : b), lk2__(a == b ? nullptr : (a < b ? b : a));
 	if (a->kind != b->kind || a->size != b->size || a->local_bytes != b->local_bytes ||
 	    a->mod.shard_lo != b->mod.shard_lo || a->device != b->device)
 		return fail(BTLBF_EINVAL, "btlbf_compare: the two filters differ in kind, size, shard range or device");
@@ -2063,6 +2116,7 @@ extern "C" int btlbf_positions_seqs(btlbf_filter* f, const char* seq, uint64_t l
                                     uint64_t* tags, uint64_t bucket_cap, uint64_t* bucket_counts,
                                     uint64_t* valid_bits, void* stream)
 {
+	FilterLock lk__(f);
 	int rc = seq_precheck(f, len);
 	if (rc)
 		return rc;
@@ -2091,6 +2145,7 @@ extern "C" int btlbf_positions_seqs(btlbf_filter* f, const char* seq, uint64_t l
 
 extern "C" int btlbf_insert_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n, void* stream)
 {
+	FilterLock lk__(f);
 	if (!f || (n && !local_pos))
 		return fail(BTLBF_EINVAL, "null argument");
 	if (f->kind != BTLBF_BLOOM)
@@ -2103,6 +2158,7 @@ extern "C" int btlbf_insert_positions(btlbf_filter* f, const uint64_t* local_pos
 extern "C" int btlbf_test_positions(btlbf_filter* f, const uint64_t* local_pos, uint64_t n, uint8_t* out,
                                     void* stream)
 {
+	FilterLock lk__(f);
 	if (!f || (n && (!local_pos || !out)))
 		return fail(BTLBF_EINVAL, "null argument");
 	if (f->kind != BTLBF_BLOOM)
@@ -2212,6 +2268,7 @@ extern "C" int btlbf_synth_reads(char* dev_out, uint64_t seed, uint64_t first_re
 extern "C" int btlbf_microbench(btlbf_filter* f, int kind, uint64_t n_access, uint64_t* n_done,
                                 double* seconds)
 {
+	FilterLock lk__(f);
 	if (!f || !seconds || !n_done)
 		return fail(BTLBF_EINVAL, "null argument");
 	{

@@ -166,10 +166,25 @@ uint64_t resync(int fd, uint64_t begin, int fmt, uint64_t file_size)
 				return ls;
 			if (fmt == btlbf_fastx::FASTA && b[0] == '>')
 				return ls;
-			if (fmt == btlbf_fastx::FASTQ && b[0] == '@' && nl1) {
-				const size_t o1 = (size_t)(nl1 - b) + 1;
-				const char* nl2 = o1 < (size_t)n ? static_cast<const char*>(memchr(b + o1, '\n', (size_t)n - o1)) : nullptr;
-				if (nl2 && (size_t)(nl2 - b) + 1 < (size_t)n && nl2[1] == '+')
+			if (fmt == btlbf_fastx::FASTQ && b[0] == '@') {
+				// the first byte of the line two below, however long the two lines in between are
+				uint64_t at = ls;
+				int lines = 0;
+				char c2 = 0;
+				std::vector<char> w(1u << 20);
+				while (lines < 2 && at < file_size) {
+					const ssize_t m = pread(fd, w.data(), w.size(), (off_t)at);
+					if (m <= 0)
+						break;
+					const char* q = static_cast<const char*>(memchr(w.data(), '\n', (size_t)m));
+					if (!q) {
+						at += (uint64_t)m;
+						continue;
+					}
+					at += (uint64_t)(q - w.data()) + 1;
+					++lines;
+				}
+				if (lines == 2 && at < file_size && pread(fd, &c2, 1, (off_t)at) == 1 && c2 == '+')
 					return ls;
 			}
 		}
@@ -599,6 +614,8 @@ int run_fastx(btlbf_filter* f, const char* path, uint32_t flags, uint64_t batch_
 		    hipEventRecord(sl.filled, copy_s) != hipSuccess || hipStreamWaitEvent(comp_s, sl.filled, 0) != hipSuccess)
 			return btlbf_set_error(BTLBF_EHIP, "fastx: stream operation failed");
 		++st.n_batches;
+		if (query && sl.nb < k) // nothing is tested: the slot's count mirror must not keep the previous batch's numbers
+			h_counts[s_ * 2 + 0] = h_counts[s_ * 2 + 1] = 0;
 		if (sl.nb >= k) {
 			btlbf_layout lay;
 			lay.starts = sl.d_starts;

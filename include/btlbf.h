@@ -17,11 +17,14 @@
  *    library stages through its own device scratch) or BTLBF_DEVICE (HBM pointers, used as-is).
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work on one filter
  *    is ordered by the stream; BTLBF_HOST calls synchronise before returning.
- *  - threads: a filter caches device scratch between calls and takes no lock -- calls on ONE filter
- *    come from one host thread at a time (the reference's per-k-mer calls are thread-safe through
- *    atomics, BloomFilter.hpp:185-194; here the parallelism is inside a batch call).  Different
- *    filters may be driven from different threads.  On one thread, btlbf_route_seqs may run on a
- *    second stream while btlbf_apply_routed* runs on the first (they share no scratch).
+ *  - threads: every entry point that takes a filter holds the filter's internal lock for its whole duration
+ *    (a filter keeps device scratch between calls), so ONE filter may be driven from many host threads -- the
+ *    calls are serialised, the parallelism is inside each batch call -- and different filters run
+ *    concurrently.  This is what makes the C++ shims safe for the reference's own threading pattern
+ *    (OpenMP threads calling insert()/contains() on one filter, Tests/AdHoc/ParallelFilter.cpp:104-122;
+ *    the reference itself relies on byte atomics, BloomFilter.hpp:177,191,206-210).  btlbf_destroy must not
+ *    race with other calls on the same filter.  On one thread, btlbf_route_seqs may run on a second
+ *    stream while btlbf_apply_routed* runs on the first (they share no scratch).
  *  - a "sequence buffer" is `len` bytes of nucleotide text.  Windows (k-mers) are identified by
  *    the byte offset p of their first base.  A window is *clean* iff all k bytes are bases the
  *    reference accepts (seedTab != 0, vendor/nthash.hpp:195-228: A C G T U, either case, and

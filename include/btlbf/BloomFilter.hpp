@@ -6,6 +6,12 @@
 //   * insert(hashes) is write-combined: rows are queued on the host and pushed to the GPU in one
 //     btlbf_insert_hashes call when the queue fills or before anything reads the filter.  Bit OR is
 //     order-free, so this is invisible to callers (reference: BloomFilter.hpp:171-194).
+//   * threads: as in the reference, insert / insertAndCheck / contains may be called on ONE filter from
+//     many threads at once (Tests/AdHoc/ParallelFilter.cpp:104-122 does so under OpenMP; the reference
+//     relies on byte atomics, BloomFilter.hpp:177,191,206-210).  Here the queue is striped -- a thread
+//     appends to the stripe its id hashes to, under that stripe's mutex -- and the C ABI underneath
+//     serialises calls on one filter with an internal lock.  storeFilter / loadFilter while other
+//     threads insert is a caller race here as it is there.
 //   * contains()/insertAndCheck() per k-mer cost one GPU round trip each; use the *Seq/*Seqs batch
 //     members (or BloomFilterUtil.h's insertSeq) on the fast path.
 //   * not reproduced on purpose: the (expectedElemNum, fpr, ...) constructor, which in the reference
@@ -16,7 +22,10 @@
 
 #include <cmath>
 #include <fstream>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 class BloomFilter
@@ -40,7 +49,8 @@ class BloomFilter
 	{
 		btlbf_destroy(m_f);
 		m_f = nullptr;
-		m_pending.clear();
+		for (auto& st : m_stripes)
+			st.rows.clear();
 		btlbf_shim::check(
 		    btlbf_load(&m_f, BTLBF_BLOOM, filterFilePath.c_str(), 0, btlbf_shim::default_device()));
 	}
@@ -49,9 +59,15 @@ class BloomFilter
 	void insert(const uint64_t precomputed[]) // BloomFilter.hpp:185-194
 	{
 		const unsigned h = getHashNum();
-		m_pending.insert(m_pending.end(), precomputed, precomputed + h);
-		if (m_pending.size() >= kFlushRows * (size_t)h)
-			flush();
+		Stripe& st = m_stripes[std::hash<std::thread::id>()(std::this_thread::get_id()) % kStripes];
+		std::lock_guard<std::mutex> g(st.mu);
+		st.rows.insert(st.rows.end(), precomputed, precomputed + h);
+		// pushed under the stripe's lock: a flush() (= any reader) that finds the stripe empty must be able to
+		// rely on its rows having reached the filter, not on their being on their way in another thread
+		if (st.rows.size() >= kFlushRows * (size_t)h) {
+			push(st.rows);
+			st.rows.clear();
+		}
 	}
 	void insert(std::vector<uint64_t> const& precomputed) // BloomFilter.hpp:171-180 (.at() range check)
 	{
@@ -224,19 +240,31 @@ class BloomFilter
 	BloomFilter(const BloomFilter&) = delete; // BloomFilter.hpp:384
 	BloomFilter& operator=(const BloomFilter&) = delete;
 
+	void push(const std::vector<uint64_t>& rows) const
+	{
+		btlbf_shim::check(btlbf_insert_hashes(m_f, rows.data(), rows.size() / getHashNum(), 0, BTLBF_ORDER_PARALLEL,
+		                                      BTLBF_HOST, nullptr));
+	}
+	// everything queued by any thread so far reaches the filter
 	void flush() const
 	{
-		if (m_pending.empty())
-			return;
-		const unsigned h = getHashNum();
-		btlbf_shim::check(btlbf_insert_hashes(m_f, m_pending.data(), m_pending.size() / h, 0,
-		                                      BTLBF_ORDER_PARALLEL, BTLBF_HOST, nullptr));
-		m_pending.clear();
+		for (auto& st : m_stripes) {
+			std::lock_guard<std::mutex> g(st.mu);
+			if (!st.rows.empty()) {
+				push(st.rows);
+				st.rows.clear();
+			}
+		}
 	}
 
 	static constexpr size_t kFlushRows = 1u << 16;
+	static constexpr size_t kStripes = 16;
+	struct Stripe {
+		std::mutex mu;
+		std::vector<uint64_t> rows;
+	};
 	btlbf_filter* m_f = nullptr;
-	mutable std::vector<uint64_t> m_pending;
+	mutable Stripe m_stripes[kStripes];
 	double m_FPR = 0;
 };
 

@@ -5,6 +5,8 @@
 // the reference.  Per-k-mer calls apply in call order (BTLBF_ORDER_SERIAL on one row), so a
 // single-threaded caller gets exactly the reference's counters; the batch members run in parallel
 // (incrementAll stays exact; insert = incrementMin is order-dependent in the reference too).
+// Threads: per-k-mer calls may come from many threads at once, as in the reference
+// (CountingBloomFilter.hpp:117-132); they are serialised by the filter's lock inside the C ABI.
 // Not reproduced: loadFilter's resize to sizeInBytes *elements* (CountingBloomFilter.hpp:275), an
 // over-allocation that only matters for T wider than a byte.
 #ifndef BTLBF_COUNTINGBLOOMFILTER_HPP
@@ -155,20 +157,25 @@ class CountingBloomFilter
 	btlbf_filter* handle() const { return m_f; }
 
   private:
-	// copy the first m_hashNum values of any indexable holder into a contiguous row
+	// the first m_hashNum values of any indexable holder as a contiguous row.  A value, not a member: the
+	// reference's per-k-mer calls may come from many threads at once (CountingBloomFilter.hpp:117-132)
+	struct Row {
+		std::vector<uint64_t> v;
+		operator const uint64_t*() const { return v.data(); }
+	};
 	template<typename U>
-	const uint64_t* row(const U& hashes) const
+	Row row(const U& hashes) const
 	{
+		Row r;
 		const unsigned h = getHashNum();
-		m_row.resize(h);
+		r.v.resize(h);
 		for (unsigned i = 0; i < h; ++i)
-			m_row[i] = hashes[i];
-		return m_row.data();
+			r.v[i] = hashes[i];
+		return r;
 	}
 
 	btlbf_filter* m_f = nullptr;
 	unsigned m_threshold = 0;
-	mutable std::vector<uint64_t> m_row;
 };
 
 #endif

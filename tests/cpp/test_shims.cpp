@@ -8,6 +8,7 @@
 #include "btlbf/ntHashIterator.hpp"
 #include "btlbf/stHashIterator.hpp"
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -256,6 +257,88 @@ static void file_loaders_equal_insert_seq()
 	std::remove(f4.c_str());
 }
 
+// synthetic reads of SURVEY.md 8d (the generator behind tests/golden/digests.json)
+static std::string synth_read(uint64_t seed, uint64_t r, unsigned len)
+{
+	auto w = [&](uint64_t n) {
+		uint64_t z = seed + (n + 1) * 0x9E3779B97F4A7C15ULL;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+		return z ^ (z >> 31);
+	};
+	const unsigned wpr = (len + 31) / 32;
+	std::string s(len, 'A');
+	for (unsigned j = 0; j < len; ++j)
+		s[j] = "ACGT"[(w(r * wpr + j / 32) >> (2 * (j % 32))) & 3];
+	return s;
+}
+
+// The reference's own multi-threaded harness, Tests/AdHoc/ParallelFilter.cpp:104-122: OpenMP threads pull
+// sequences from one stream inside a critical section and each runs the ntHashIterator + bloom.insert(*itr)
+// loop on ONE shared filter; here also with concurrent contains() while the others insert.  The filter is
+// golden fixture bf_small (tests/golden/digests.json): written to `out_path`, the Python wrapper compares
+// its body digest with the reference's.
+static void parallel_filter_replay(const char* out_path)
+{
+	const unsigned n_reads = 20000, L = 150, h = 4, k = 31;
+	BloomFilter bloom(1 << 24, h, k);
+	unsigned next = 0;
+	std::atomic<unsigned long> inserted(0), found(0), asked(0);
+#pragma omp parallel
+	{
+		for (;;) {
+			std::string seq;
+			bool good = false;
+#pragma omp critical(uFile)
+			{
+				if (next < n_reads) {
+					seq = synth_read(42, next++, L);
+					good = true;
+				}
+			}
+			if (!good)
+				break;
+			ntHashIterator itr(seq, h, k);
+			unsigned long n = 0;
+			while (itr != itr.end()) {
+				bloom.insert(*itr);
+				++itr;
+				++n;
+			}
+			inserted += n;
+			if (next % 64 == 0) { // a reader among the writers: this thread's own k-mers must be there
+				ntHashIterator q(seq, h, k);
+				while (q != q.end()) {
+					found += bloom.contains(*q);
+					++asked;
+					++q;
+				}
+			}
+		}
+	}
+	CHECK(inserted == (unsigned long)n_reads * (L - k + 1));
+	CHECK(asked > 0 && found == asked);
+	CHECK(bloom.getPop() == 7310180); // digests.json: bf_small.pop (the reference's count)
+	if (out_path)
+		bloom.storeFilter(out_path);
+	// counting filter: increments from many threads are serialised, none is lost (incrementAll is exact)
+	CountingBloomFilter<uint8_t> cbf(1 << 16, 3, 25, 2);
+	const std::string s = synth_read(7, 0, 80);
+#pragma omp parallel for
+	for (int t = 0; t < 64; ++t) {
+		ntHashIterator it(s, 3, 25);
+		while (it != it.end()) {
+			cbf.incrementAll(*it);
+			++it;
+		}
+	}
+	ntHashIterator c(s, 3, 25);
+	while (c != c.end()) {
+		CHECK(cbf.minCount(*c) >= 64);
+		++c;
+	}
+}
+
 int main(int argc, char** argv)
 {
 	bloom_basic();
@@ -263,6 +346,7 @@ int main(int argc, char** argv)
 	counting_basic();
 	fused_path_equals_iterator_path(argc > 1 ? argv[1] : nullptr);
 	file_loaders_equal_insert_seq();
+	parallel_filter_replay(argc > 2 ? argv[2] : nullptr);
 	if (g_fail) {
 		std::fprintf(stderr, "%d checks failed\n", g_fail);
 		return 1;

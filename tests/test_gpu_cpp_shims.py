@@ -20,15 +20,27 @@ def test_shim_headers_compile_on_cpu():
 
 
 @pytest.mark.gpu
-def test_reference_unit_scenarios_through_shims():
+def test_reference_unit_scenarios_through_shims(tmp_path):
     import __graft_entry__ as g
     from btl_bloomfilter_amd import build
 
     build.build()
     exe = g.build_shim_test()
-    r = subprocess.run([exe, GOLDEN], capture_output=True, text=True, timeout=600)
+    out = tmp_path / "parallel.bf"
+    r = subprocess.run([exe, GOLDEN, str(out)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, OMP_NUM_THREADS="8"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all shim tests passed" in r.stdout
+    # the filter built by 8 OpenMP threads calling bloom.insert(*itr) on one BloomFilter (the reference's
+    # Tests/AdHoc/ParallelFilter.cpp pattern) is the reference's own filter, byte for byte
+    import hashlib
+
+    from conftest import load_golden
+
+    g = load_golden("digests.json")["bf_small"]
+    data = out.read_bytes()
+    body = data[data.index(b"[HeaderEnd]\n") + len(b"[HeaderEnd]\n"):]
+    assert len(body) == g["bits"] // 8 and hashlib.sha256(body).hexdigest() == g["body_sha256"]
 
 
 @pytest.mark.gpu
