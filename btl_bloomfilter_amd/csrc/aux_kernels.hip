@@ -6,7 +6,7 @@
 //     CountingBloomFilter.hpp:217-242)
 //   * synthetic read generator and the random-access microbenchmarks
 //   * shard-local position insert/test and the origin-side AND of routed answers
-#include "device_utils.hpp"
+#include "seq_core.hpp"
 
 namespace btlbf {
 
@@ -458,6 +458,268 @@ hipError_t launch_count_per_seq(const uint64_t* hit_bits, const uint64_t* valid_
 		blocks = 65536;
 	hipLaunchKernelGGL(count_per_seq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, hit_bits, valid_bits, len, starts,
 	                   n_seqs, read_len, k, hits_out, valid_out);
+	return hipGetLastError();
+}
+
+// ---- split query (fixed-length reads): likely-present and likely-absent reads take different paths ----
+// contains() over a buffer whose misses come clustered by read (reads foreign to the indexed genome next to
+// reads from it -- what a classifier feeds a filter): the partitioned path is fast when nearly every k-mer
+// hits, the early-exit gather kernel when nearly none does.  So every read is SAMPLED (three of its windows,
+// full contains() each), reads whose clean samples all miss are "cold", the buffer is compacted into a warm
+// and a cold buffer, each goes down its own path, and the two bitmaps are merged back into the caller's
+// layout.  Every path computes the exact contains(), so the sampling only steers speed.
+
+// one lane per sampled read (read i * stride).  A read is COLD when most of its clean samples miss (two of
+// three: a single false positive or a single SNP does not flip the call).  stride == 1: flags bit (r & 63) of
+// word r >> 6 = read r is cold.  *n_cold += cold reads among the sampled ones.
+__global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, uint64_t n_reads, uint32_t L, uint32_t stride,
+                                                          const HashParams hp, const ModParams mod, const void* filter,
+                                                          uint32_t counting, uint32_t threshold,
+                                                          unsigned long long* flags, unsigned long long* n_cold)
+{
+	__shared__ uint64_t tab[kNumCodes][2]; // Horner start-up seeds per base code (HashParams::init_tab)
+	if (threadIdx.x < kNumCodes * 2)
+		tab[threadIdx.x >> 1][threadIdx.x & 1] = hp.init_tab[threadIdx.x >> 1][threadIdx.x & 1];
+	__syncthreads();
+	const uint64_t i_s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	// stride > 1: a pseudo-random read of every block of `stride` reads, so that input with a period (every
+	// other read foreign, say) is not sampled in step with it
+	const uint64_t r = i_s * stride + (stride > 1 ? mix64(i_s) % stride : 0);
+	const uint32_t k = hp.k, W = L - k + 1;
+	bool cold = false;
+	if (r < n_reads) {
+		const uint8_t* rd = seq + r * L;
+		const uint32_t offs[3] = {0, W / 2, W - 1};
+		uint32_t clean = 0, misses = 0;
+		for (int sidx = 0; sidx < 3; ++sidx) {
+			if (sidx && offs[sidx] == offs[sidx - 1])
+				continue;
+			const uint8_t* w = rd + offs[sidx];
+			uint64_t fh = 0, rh = 0;
+			uint32_t ok = kBaseValid;
+			uint32_t i = 0;
+			for (; i + 4 <= k; i += 4) { // four bases per (unaligned) load
+				uint32_t word;
+				__builtin_memcpy(&word, w + i, 4);
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					const uint32_t e = base_entry((word >> (8 * b)) & 0xff);
+					ok &= e;
+					fh = srol1(fh) ^ tab[e >> kCodeShift][0];
+					rh = sror1(rh) ^ tab[e >> kCodeShift][1];
+				}
+			}
+			for (; i < k; ++i) {
+				const uint32_t e = base_entry(w[i]);
+				ok &= e;
+				fh = srol1(fh) ^ tab[e >> kCodeShift][0];
+				rh = sror1(rh) ^ tab[e >> kCodeShift][1];
+			}
+			if (!(ok & kBaseValid))
+				continue;
+			++clean;
+			const uint64_t b = rh < fh ? rh : fh;
+			bool hit = true;
+			for (uint32_t j = 0; j < hp.h && hit; ++j) {
+				const uint64_t hv = j ? extra_hash(b, hp.kms, j) : b;
+				const uint64_t p = mod.pow2 ? (hv & mod.mask) : reduce_mod<false>(hv, mod);
+				if (counting)
+					hit = cbf_read_fresh(static_cast<const uint32_t*>(filter), p) >= threshold;
+				else
+					hit = (bf_word(static_cast<const uint32_t*>(filter), p) >> (p & 31)) & 1u;
+			}
+			misses += !hit;
+		}
+		cold = clean > 0 && 2 * misses > clean;
+	}
+	const unsigned long long m = __ballot(cold);
+	if ((threadIdx.x & 63) == 0) {
+		if (stride == 1 && r < n_reads)
+			flags[r >> 6] = m;
+		if (m)
+			atomicAdd(n_cold, (unsigned long long)__popcll(m));
+	}
+}
+
+// prefix[w] = cold reads before flag word w.  Three tiny passes: per-chunk sums (1024 words a chunk), a serial
+// exclusive scan of the chunk sums by one thread (at most ~16 K chunks for 10^9 reads), then each word's
+// prefix from its chunk's base
+__global__ __launch_bounds__(1024) void flag_chunk_sum_kernel(const unsigned long long* flags, uint64_t n_words,
+                                                             uint32_t* chunk_sum)
+{
+	__shared__ uint32_t acc;
+	if (threadIdx.x == 0)
+		acc = 0;
+	__syncthreads();
+	const uint64_t w = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+	uint32_t c = w < n_words ? (uint32_t)__popcll(flags[w]) : 0;
+	c = wave_sum(c);
+	if ((threadIdx.x & 63) == 0 && c)
+		atomicAdd(&acc, c);
+	__syncthreads();
+	if (threadIdx.x == 0)
+		chunk_sum[blockIdx.x] = acc;
+}
+__global__ void flag_chunk_scan_kernel(uint32_t* chunk_sum, uint32_t n_chunks)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		uint32_t run = 0;
+		for (uint32_t i = 0; i < n_chunks; ++i) {
+			const uint32_t v = chunk_sum[i];
+			chunk_sum[i] = run;
+			run += v;
+		}
+	}
+}
+__global__ __launch_bounds__(1024) void flag_prefix_kernel(const unsigned long long* flags, uint64_t n_words,
+                                                          const uint32_t* chunk_base, uint32_t* prefix)
+{
+	__shared__ uint32_t wave_tot[16];
+	const uint64_t w = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+	const uint32_t c = w < n_words ? (uint32_t)__popcll(flags[w]) : 0;
+	const uint32_t incl = wave_scan_incl(c);
+	if ((threadIdx.x & 63) == 63)
+		wave_tot[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	uint32_t base = chunk_base[blockIdx.x];
+	for (uint32_t v = 0; v < (threadIdx.x >> 6); ++v)
+		base += wave_tot[v];
+	if (w < n_words)
+		prefix[w] = base + incl - c;
+}
+
+__device__ __forceinline__ uint32_t cold_rank(const unsigned long long* flags, const uint32_t* prefix, uint64_t r,
+                                              bool* cold)
+{
+	const unsigned long long m = flags[r >> 6];
+	*cold = (m >> (r & 63)) & 1ull;
+	return prefix[r >> 6] + (uint32_t)__popcll(m & ((1ull << (r & 63)) - 1));
+}
+
+// one wave per 8 reads: read r goes to cold_buf[rank * L] or warm_buf[(r - rank) * L]
+__global__ __launch_bounds__(256) void compact_reads_kernel(const uint8_t* seq, uint64_t n_reads, uint32_t L,
+                                                            const unsigned long long* flags, const uint32_t* prefix,
+                                                            uint8_t* warm_buf, uint8_t* cold_buf)
+{
+	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t lane = threadIdx.x & 63;
+	for (uint32_t q = 0; q < 8; ++q) {
+		const uint64_t r = wave * 8 + q;
+		if (r >= n_reads)
+			return;
+		bool cold;
+		const uint32_t rk = cold_rank(flags, prefix, r, &cold);
+		const uint8_t* src = seq + r * L;
+		uint8_t* dst = cold ? cold_buf + (uint64_t)rk * L : warm_buf + (r - rk) * L;
+		for (uint32_t o = lane * 4; o < L; o += 256) {
+			if (o + 4 <= L) {
+				uint32_t v;
+				__builtin_memcpy(&v, src + o, 4);
+				__builtin_memcpy(dst + o, &v, 4);
+			} else {
+				for (uint32_t b = o; b < L; ++b)
+					dst[b] = src[b];
+			}
+		}
+	}
+}
+
+// bits [pos, pos + n) of a bitmap (n <= 64), little-endian bit order
+__device__ __forceinline__ uint64_t bits_at(const uint64_t* bm, uint64_t pos, uint32_t n)
+{
+	const uint64_t w = pos >> 6;
+	const uint32_t sh = (uint32_t)(pos & 63);
+	uint64_t v = bm[w] >> sh;
+	if (sh + n > 64)
+		v |= bm[w + 1] << (64 - sh);
+	return n == 64 ? v : v & ((1ull << n) - 1);
+}
+
+// one thread per word of the caller's bitmaps: the bits of the reads that overlap it, fetched from the warm /
+// cold bitmaps (over the compacted buffers, which are padded by one word)
+__global__ __launch_bounds__(256) void merge_split_bitmaps_kernel(uint64_t n_words, uint64_t len, uint32_t L,
+                                                                  const unsigned long long* flags, const uint32_t* prefix,
+                                                                  const uint64_t* warm_hit, const uint64_t* cold_hit,
+                                                                  const uint64_t* warm_valid, const uint64_t* cold_valid,
+                                                                  uint64_t* hit_out, uint64_t* valid_out)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_words)
+		return;
+	uint64_t b0 = w * 64, b1 = b0 + 64;
+	if (b1 > len)
+		b1 = len;
+	uint64_t hit = 0, valid = 0;
+	for (uint64_t r = b0 / L; b0 < b1; ++r) {
+		const uint64_t r_end = (r + 1) * L;
+		const uint64_t e = r_end < b1 ? r_end : b1;
+		const uint32_t n = (uint32_t)(e - b0);
+		bool cold;
+		const uint32_t rk = cold_rank(flags, prefix, r, &cold);
+		const uint64_t src = (cold ? (uint64_t)rk : r - rk) * L + (b0 - r * L);
+		const uint32_t sh = (uint32_t)(b0 - w * 64);
+		if (hit_out)
+			hit |= bits_at(cold ? cold_hit : warm_hit, src, n) << sh;
+		if (valid_out)
+			valid |= bits_at(cold ? cold_valid : warm_valid, src, n) << sh;
+		b0 = e;
+	}
+	if (hit_out)
+		hit_out[w] = hit;
+	if (valid_out)
+		valid_out[w] = valid;
+}
+
+// stride > 1: only every stride-th read is sampled and only *n_cold is produced (a cheap estimate)
+hipError_t launch_read_sample(const uint8_t* seq, uint64_t n_reads, uint32_t L, uint32_t stride, const HashParams& hp,
+                              const ModParams& mod, const void* filter, int counting, uint32_t threshold, uint64_t* flags,
+                              uint64_t* n_cold, hipStream_t s)
+{
+	if (n_reads == 0 || stride == 0)
+		return hipSuccess;
+	const uint64_t n_s = (n_reads + stride - 1) / stride;
+	hipLaunchKernelGGL(read_sample_kernel, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, seq, n_reads, L, stride, hp, mod,
+	                   filter, (uint32_t)counting, threshold, reinterpret_cast<unsigned long long*>(flags),
+	                   reinterpret_cast<unsigned long long*>(n_cold));
+	return hipGetLastError();
+}
+
+// prefix must hold ceil(n_reads / 64) uint32 + one uint32 per 1024 of those (scratch behind it)
+hipError_t launch_flag_prefix(const uint64_t* flags, uint64_t n_reads, uint32_t* prefix, hipStream_t s)
+{
+	const uint64_t n_words = (n_reads + 63) / 64;
+	if (n_words == 0)
+		return hipSuccess;
+	const uint32_t n_chunks = (uint32_t)((n_words + 1023) / 1024);
+	uint32_t* chunk = prefix + n_words;
+	const unsigned long long* fl = reinterpret_cast<const unsigned long long*>(flags);
+	hipLaunchKernelGGL(flag_chunk_sum_kernel, dim3(n_chunks), dim3(1024), 0, s, fl, n_words, chunk);
+	hipLaunchKernelGGL(flag_chunk_scan_kernel, dim3(1), dim3(64), 0, s, chunk, n_chunks);
+	hipLaunchKernelGGL(flag_prefix_kernel, dim3(n_chunks), dim3(1024), 0, s, fl, n_words, chunk, prefix);
+	return hipGetLastError();
+}
+
+hipError_t launch_compact_reads(const uint8_t* seq, uint64_t n_reads, uint32_t L, const uint64_t* flags,
+                                const uint32_t* prefix, uint8_t* warm_buf, uint8_t* cold_buf, hipStream_t s)
+{
+	if (n_reads == 0)
+		return hipSuccess;
+	const uint64_t waves = (n_reads + 7) / 8;
+	hipLaunchKernelGGL(compact_reads_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, seq, n_reads, L,
+	                   reinterpret_cast<const unsigned long long*>(flags), prefix, warm_buf, cold_buf);
+	return hipGetLastError();
+}
+
+hipError_t launch_merge_split_bitmaps(uint64_t len, uint32_t L, const uint64_t* flags, const uint32_t* prefix,
+                                      const uint64_t* warm_hit, const uint64_t* cold_hit, const uint64_t* warm_valid,
+                                      const uint64_t* cold_valid, uint64_t* hit_out, uint64_t* valid_out, hipStream_t s)
+{
+	const uint64_t n_words = (len + 63) / 64;
+	if (n_words == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(merge_split_bitmaps_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, n_words, len, L,
+	                   reinterpret_cast<const unsigned long long*>(flags), prefix, warm_hit, cold_hit, warm_valid, cold_valid,
+	                   hit_out, valid_out);
 	return hipGetLastError();
 }
 

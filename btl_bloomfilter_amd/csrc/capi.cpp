@@ -96,6 +96,10 @@ struct btlbf_filter {
 	int query_mode = BTLBF_INSERT_AUTO;
 	void* d_part = nullptr;
 	uint64_t part_bytes = 0;
+	void* d_split = nullptr; // split query: compacted reads + their bitmaps, cached like d_part
+	uint64_t split_bytes = 0;
+	void* d_flags = nullptr; // split query: cold flags of the reads + their prefix sums (small)
+	uint64_t flags_bytes = 0;
 	uint64_t part_budget = 0; // 0 = derive from free HBM
 	// optional per-kernel timing with HIP events on the launch stream (btlbf_set_profiling)
 	bool profiling = false;
@@ -594,6 +598,8 @@ extern "C" int btlbf_destroy(btlbf_filter* f)
 	(void)hipFree(f->d_pos_tab);
 	(void)hipFree(f->d_dc_idx);
 	(void)hipFree(f->d_part);
+	(void)hipFree(f->d_split);
+	(void)hipFree(f->d_flags);
 	delete f;
 	return BTLBF_OK;
 }
@@ -617,6 +623,12 @@ extern "C" int btlbf_release_scratch(btlbf_filter* f)
 	(void)hipFree(f->d_part); // synchronises with work in flight
 	f->d_part = nullptr;
 	f->part_bytes = 0;
+	(void)hipFree(f->d_split);
+	f->d_split = nullptr;
+	f->split_bytes = 0;
+	(void)hipFree(f->d_flags);
+	f->d_flags = nullptr;
+	f->flags_bytes = 0;
 	return BTLBF_OK;
 }
 
@@ -906,6 +918,7 @@ namespace {
 int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, uint8_t* valid_bits,
                          uint64_t* counts, hipStream_t s, bool* done);
 int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* yes);
+int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t s, int* decided);
 
 int seq_precheck(const btlbf_filter* f, uint64_t len)
 {
@@ -985,7 +998,12 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 	bool done = false;
 	if (op == OP_BF_CONTAINS || op == OP_BF_CONTAINS_WIN || (op == OP_CBF_QUERY && !min_out)) { // minimum counts need the values: direct
 		bool yes = false;
-		if ((rc = want_partitioned_query(f, a, s, &yes)))
+		int decided = 0; // split_contains: 0 = not applicable, 1 = direct, 2 = partitioned, 3 = done
+		if (op != OP_BF_CONTAINS_WIN && (rc = split_contains(f, a, op, s, &decided)))
+			return rc;
+		done = decided == 3;
+		yes = decided == 2;
+		if (decided == 0 && (rc = want_partitioned_query(f, a, s, &yes)))
 			return rc;
 		if (yes) {
 			DevBuf tmp_hit; // the partitioned path needs a hit bitmap to refine even if the caller wants counts only
@@ -1353,10 +1371,15 @@ int resolve_range(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, const
 	d.hit_bits = hit_bits;
 	d.valid_bits = nullptr;
 	d.counts = nullptr;
-	HIP_TRY(hipMemsetAsync(table, 0, kFailTableSlots * 8, s));
-	HIP_TRY(launch_failset_build(fail_list, n_fail, table, kFailTableSlots - 1, s));
+	// the table is sized to the set (load <= 1/4): a few thousand failed positions make a table that stays in
+	// L2, and every probe of every window of the range is looked up in it
+	uint64_t slots = 1024;
+	while (slots < 4 * n_fail && slots < kFailTableSlots)
+		slots <<= 1;
+	HIP_TRY(hipMemsetAsync(table, 0, slots * 8, s));
+	HIP_TRY(launch_failset_build(fail_list, n_fail, table, slots - 1, s));
 	d.buckets = table;
-	d.bucket_cap = kFailTableSlots - 1;
+	d.bucket_cap = slots - 1;
 	HIP_TRY(launch_seq_op(OP_BF_RESOLVE, d, s));
 	return BTLBF_OK;
 }
@@ -1479,6 +1502,168 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 	// what the fail list holds per batch
 	const double miss = (double)(c[0] - c[1]) / (double)c[0];
 	*yes = miss * live < 0.25 * (double)kFailCap;
+	return BTLBF_OK;
+}
+
+// contains() over fixed-length reads in AUTO mode (aux_kernels.hip, "split query"): sample every read; if the
+// misses are few enough for the fail list the whole buffer goes partitioned (*decided = 2), if hardly anything
+// hits it goes to the gather kernel (1); otherwise the reads are compacted into a warm and a cold buffer, the
+// warm one takes the partitioned path, the cold one the early-exit gather kernel, and the two bitmaps are
+// merged back into the caller's layout (3: a.hit_bits / a.valid_bits / a.counts are complete).
+int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t s, int* decided)
+{
+	*decided = 0;
+	const uint32_t L = a.layout.starts ? 0 : a.layout.read_len, k = f->hp.k;
+	if (f->query_mode != BTLBF_INSERT_AUTO || !L || L < k || L < 8 || f->hp.n_seeds || !part_supported_h(f->hp.h))
+		return BTLBF_OK;
+	const uint64_t n_reads = a.len / L;
+	const uint32_t W = L - k + 1;
+	const double live = (double)n_reads * W * f->hp.h;
+	if (live < 0.02 * (double)f->local_bytes || live < 4.0e6 || n_reads >= (1ull << 32))
+		return BTLBF_OK; // small batches: the direct kernel (want_partitioned_query agrees)
+	const uint64_t n_fw = (n_reads + 63) / 64;
+	// temporaries are cached in the filter (grow-only, btlbf_release_scratch returns them): hipMalloc / hipFree
+	// of tens of GB cost more than the kernels.  The small one (flags, prefix sums) is needed by every call;
+	// the large one (compacted reads, their bitmaps) only once the split path is taken
+	auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+	auto grow = [](void** p, uint64_t* have, uint64_t bytes) -> bool {
+		if (bytes <= *have)
+			return true;
+		(void)hipFree(*p);
+		*p = nullptr;
+		*have = 0;
+		if (hipMalloc(p, bytes) != hipSuccess) {
+			(void)hipGetLastError();
+			return false;
+		}
+		*have = bytes;
+		return true;
+	};
+	const uint64_t sz_flags = up(n_fw * 8 + 8), sz_prefix = up((n_fw + (n_fw + 1023) / 1024 + 1) * 4);
+	if (!grow(&f->d_flags, &f->flags_bytes, 256 + sz_flags + sz_prefix))
+		return BTLBF_OK; // no room: the plain paths decide (want_partitioned_query)
+	unsigned long long* d_ncold = static_cast<unsigned long long*>(f->d_flags);
+	uint64_t* d_flags = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(f->d_flags) + 256);
+	uint32_t* d_prefix = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(f->d_flags) + 256 + sz_flags);
+	unsigned long long n_cold = 0;
+	auto sample = [&](uint32_t stride) -> int {
+		HIP_TRY(hipMemsetAsync(d_ncold, 0, 8, s));
+		{
+			ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
+			HIP_TRY(launch_read_sample(a.seq, n_reads, L, stride, f->hp, f->mod, f->d_data, f->kind == BTLBF_COUNTING8,
+			                           f->thr, d_flags, reinterpret_cast<uint64_t*>(d_ncold), s));
+		}
+		HIP_TRY(hipMemcpyAsync(&n_cold, d_ncold, 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		return BTLBF_OK;
+	};
+	// what the fail list copes with / what is worth a sweep of the array, in reads
+	const double few_cold = 0.25 * (double)kFailCap / ((double)W * f->hp.h);
+	auto warm_too_few = [&](double n_warm_reads) {
+		const double wl = n_warm_reads * W * f->hp.h;
+		return wl < 0.02 * (double)f->local_bytes || wl < 4.0e6;
+	};
+	// 1. an estimate from one read in 64: all-hit and all-miss buffers -- the common cases -- are recognised at
+	//    1/64 of the cost of looking at every read
+	int rc;
+	const uint32_t stride = n_reads >= (1u << 20) ? 64 : 1;
+	if (stride > 1) {
+		if ((rc = sample(stride)))
+			return rc;
+		const uint64_t n_s = (n_reads + stride - 1) / stride;
+		if (n_cold == 0 && (double)n_reads * 8.0 / (double)n_s < few_cold) { // none in the sample: few overall
+			*decided = 2;
+			return BTLBF_OK;
+		}
+		if (warm_too_few((double)(n_s - n_cold) * stride * 1.5)) {
+			*decided = 1;
+			return BTLBF_OK;
+		}
+	}
+	// 2. every read
+	if ((rc = sample(1)))
+		return rc;
+	const uint64_t n_warm = n_reads - n_cold;
+	if ((double)n_cold < few_cold) { // the fail list copes with that many misses
+		*decided = 2;
+		return BTLBF_OK;
+	}
+	if (warm_too_few((double)n_warm)) { // not worth a sweep of the array
+		*decided = 1;
+		return BTLBF_OK;
+	}
+	// ---- split ----
+	const uint64_t warm_len = n_warm * L, cold_len = n_cold * L;
+	const bool wv = a.valid_bits != nullptr;
+	const uint64_t sz[6] = {up(warm_len + 16), up(cold_len + 16), up(bitmap_bytes(warm_len) + 16),
+	                        up(bitmap_bytes(cold_len) + 16), wv ? up(bitmap_bytes(warm_len) + 16) : 0,
+	                        wv ? up(bitmap_bytes(cold_len) + 16) : 0};
+	// sized for any split of a buffer this long, so that the next call's ratio does not move memory
+	const uint64_t worst = up(a.len + 32) + 512 + (wv ? 2 : 1) * (up(bitmap_bytes(a.len) + 32) + 512);
+	if (!grow(&f->d_split, &f->split_bytes, worst)) {
+		*decided = 1; // no room for the compacted copies: the gather kernel answers any mix
+		return BTLBF_OK;
+	}
+	uint8_t* bufs[6];
+	{
+		uint64_t off = 0;
+		for (int i = 0; i < 6; ++i) {
+			bufs[i] = sz[i] ? static_cast<uint8_t*>(f->d_split) + off : nullptr;
+			off += sz[i];
+		}
+		if (off > f->split_bytes)
+			return fail(BTLBF_EINVAL, "split query: buffer arithmetic");
+	}
+	uint8_t *warm_p = bufs[0], *cold_p = bufs[1], *warm_hit_p = bufs[2], *cold_hit_p = bufs[3], *warm_valid_p = bufs[4],
+	        *cold_valid_p = bufs[5];
+	{
+		ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
+		HIP_TRY(launch_flag_prefix(d_flags, n_reads, d_prefix, s));
+		HIP_TRY(launch_compact_reads(a.seq, n_reads, L, d_flags, d_prefix, warm_p, cold_p, s));
+		// the merge reads one word past the last bit of a compacted bitmap
+		HIP_TRY(hipMemsetAsync(warm_hit_p + bitmap_bytes(warm_len), 0, 16, s));
+		HIP_TRY(hipMemsetAsync(cold_hit_p + bitmap_bytes(cold_len), 0, 16, s));
+		if (a.valid_bits) {
+			HIP_TRY(hipMemsetAsync(warm_valid_p + bitmap_bytes(warm_len), 0, 16, s));
+			HIP_TRY(hipMemsetAsync(cold_valid_p + bitmap_bytes(cold_len), 0, 16, s));
+		}
+	}
+	if (a.counts)
+		HIP_TRY(hipMemsetAsync(a.counts, 0, 16, s));
+	SeqArgs b = a;
+	b.seq = warm_p;
+	b.len = warm_len;
+	b.hit_bits = b.valid_bits = nullptr;
+	b.counts = nullptr;
+	bool done_w = false;
+	rc = partitioned_contains(f, b, warm_hit_p, warm_valid_p, a.counts, s, &done_w);
+	if (rc)
+		return rc;
+	if (!done_w) { // no room for the partition scratch: the gather kernel does the warm reads too
+		b.hit_bits = warm_hit_p;
+		b.valid_bits = warm_valid_p;
+		b.counts = a.counts;
+		ProfSpan ps(f, BTLBF_PROF_QUERY_DIRECT, s);
+		HIP_TRY(launch_seq_op(direct_op, b, s));
+	}
+	SeqArgs d = a;
+	d.seq = cold_p;
+	d.len = cold_len;
+	d.hit_bits = cold_hit_p;
+	d.valid_bits = cold_valid_p;
+	d.counts = a.counts; // the direct kernel ADDS its clean windows and hits
+	{
+		ProfSpan ps(f, BTLBF_PROF_QUERY_DIRECT, s);
+		HIP_TRY(launch_seq_op(direct_op, d, s));
+	}
+	if (a.hit_bits || a.valid_bits) {
+		ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
+		HIP_TRY(launch_merge_split_bitmaps(a.len, L, d_flags, d_prefix, reinterpret_cast<uint64_t*>(warm_hit_p),
+		                                   reinterpret_cast<uint64_t*>(cold_hit_p), reinterpret_cast<uint64_t*>(warm_valid_p),
+		                                   reinterpret_cast<uint64_t*>(cold_valid_p), reinterpret_cast<uint64_t*>(a.hit_bits),
+		                                   reinterpret_cast<uint64_t*>(a.valid_bits), s));
+	}
+	*decided = 3;
 	return BTLBF_OK;
 }
 

@@ -209,6 +209,17 @@ hipError_t launch_count_per_seq(const uint64_t* hit_bits, const uint64_t* valid_
 hipError_t launch_and_answers(const uint64_t* tags, const uint8_t* answers, uint64_t n, uint32_t h,
                               uint64_t* hit_bits, hipStream_t s);
 
+// split query (aux_kernels.hip): per-read sampling, cold-read ranks, compaction, bitmap merge
+hipError_t launch_read_sample(const uint8_t* seq, uint64_t n_reads, uint32_t L, uint32_t stride, const HashParams& hp,
+                              const ModParams& mod, const void* filter, int counting, uint32_t threshold, uint64_t* flags,
+                              uint64_t* n_cold, hipStream_t s);
+hipError_t launch_flag_prefix(const uint64_t* flags, uint64_t n_reads, uint32_t* prefix, hipStream_t s);
+hipError_t launch_compact_reads(const uint8_t* seq, uint64_t n_reads, uint32_t L, const uint64_t* flags,
+                                const uint32_t* prefix, uint8_t* warm_buf, uint8_t* cold_buf, hipStream_t s);
+hipError_t launch_merge_split_bitmaps(uint64_t len, uint32_t L, const uint64_t* flags, const uint32_t* prefix,
+                                      const uint64_t* warm_hit, const uint64_t* cold_hit, const uint64_t* warm_valid,
+                                      const uint64_t* cold_valid, uint64_t* hit_out, uint64_t* valid_out, hipStream_t s);
+
 int seq_tile_windows(); // windows per workgroup tile (for host-side sizing)
 
 } // namespace btlbf

@@ -595,7 +595,8 @@ def test_partitioned_spaced_seeds_and_shard(bf):
 # ---------------------------------------------------------------------------------------------
 # partitioned contains(): test in LDS + failed-position set; must equal the direct gather kernel
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("bits,miss_reads", [(1 << 30, 0), (1 << 30, 3), (1 << 30, 4000), (3 << 22, 50), (1 << 33, 7)])
+@pytest.mark.parametrize("bits,miss_reads", [(1 << 30, 0), (1 << 30, 3), (1 << 30, 4000), (3 << 22, 50), (1 << 33, 7),
+                                             (1 << 30, 20000), (1 << 30, 39000), (3 << 28, 10000)])
 def test_partitioned_query_equals_direct(bf, bits, miss_reads):
     import torch
 
@@ -629,9 +630,23 @@ def test_partitioned_query_equals_direct(bf, bits, miss_reads):
     flt.setQueryMode("partitioned")
     _, _, cnt = flt.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
     assert cnt.cpu().tolist() == out["direct"][2]
+    # auto mode: 10 % / 50 % / 97 % foreign reads take the split path (reads sampled, warm reads partitioned,
+    # cold reads through the gather kernel, bitmaps merged); with and without the valid bitmap, counts only
     flt.setQueryMode("auto")
+    flt.setProfiling(True)
+    flt.getProfile()
     hit, _, cnt = flt.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
     assert cnt.cpu().tolist() == out["direct"][2] and (hit.cpu().numpy() == out["direct"][0]).all()
+    prof = flt.getProfile()
+    if bits == 1 << 30 and 4000 <= miss_reads <= 20000:
+        assert "query_hash" in prof and "query_direct" in prof and "query_resolve" in prof, prof  # the split path ran
+    hit, valid, cnt = flt.containsSeqs(q, read_len=L, want_valid=True, want_counts=True)
+    assert cnt.cpu().tolist() == out["direct"][2]
+    assert (hit.cpu().numpy() == out["direct"][0]).all() and (valid.cpu().numpy() == out["direct"][1]).all()
+    # a buffer that does not end on a word boundary of the bitmaps
+    hit, valid, _ = flt.containsSeqs(q[: (n - 3) * L], read_len=L, want_valid=True, want_counts=False)
+    nb = ((n - 3) * L) // 64
+    assert (hit.cpu().numpy()[:nb] == out["direct"][0][:nb]).all() and (valid.cpu().numpy()[:nb] == out["direct"][1][:nb]).all()
 
 
 # ---------------------------------------------------------------------------------------------
