@@ -6,7 +6,7 @@ CountingBloomFilter insert / contains / insertAndCheck, ntHashIterator / stHashI
 streams, BTLBloomFilter_v1 files).  There is no CPU implementation behind them."""
 from . import _lib  # noqa: F401
 from .engine import (BloomFilter, KmerBloomFilter, insertSeq, CountingBloomFilter, hash_seqs, sthash_seqs, synth_reads_device,  # noqa: F401
-                     bits_to_bool, fastx_batches, count_per_seq)
+                     bits_to_bool, fastx_batches, count_per_seq, RankSupport)
 
 __all__ = ["BloomFilter", "KmerBloomFilter", "insertSeq", "CountingBloomFilter", "hash_seqs", "sthash_seqs", "synth_reads_device",
-           "bits_to_bool", "fastx_batches", "count_per_seq"]
+           "bits_to_bool", "fastx_batches", "count_per_seq", "RankSupport"]

@@ -77,6 +77,12 @@ _PROTOS = {
     "btlbf_set_query_mode": (C.c_int, [_P, C.c_int]),
     "btlbf_set_spaced_seeds": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_uint, C.c_uint]),
     "btlbf_compare": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
+    "btlbf_rank_create": (C.c_int, [C.POINTER(_P), _P]),
+    "btlbf_rank_destroy": (None, [_P]),
+    "btlbf_rank_ones": (C.c_uint64, [_P]),
+    "btlbf_rank_words": (C.c_uint64, [_P]),
+    "btlbf_rank_download": (C.c_int, [_P, _P]),
+    "btlbf_rank_query": (C.c_int, [_P, _P, C.c_uint64, C.c_int, _P, _P, C.c_int, _P]),
     "btlbf_insert_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_int, C.c_int, C.c_int, _P]),
     "btlbf_contains_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), _P, _P, _P, C.c_int, _P]),
     "btlbf_insert_and_check_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), _P, _P, _P, C.c_int, _P]),

@@ -723,4 +723,179 @@ hipError_t launch_merge_split_bitmaps(uint64_t len, uint32_t L, const uint64_t* 
 	return hipGetLastError();
 }
 
+// ---- rank structure over a bit filter (miBF stage 2: sdsl::bit_vector_il<512> + rank_support_il<1>) --------
+// The reference's multi-index Bloom filter turns a set bit's position into an index of its ID array with
+// rank(pos) = number of set bits before pos (MIBloomFilter.hpp:527 getRankPos, :324,391,443,461,488,509,522),
+// over sdsl's INTERLEAVED bit vector (MIBloomFilter.hpp:44,133,144,801-803): the bit vector cut into blocks of
+// 512 bits, each preceded by one 64-bit word holding the number of set bits before the block, so that one
+// rank query touches one 72-byte record.  sdsl-lite is not vendored with the reference (SURVEY.md section 2,
+// row 9); this is its published layout: record b = { ones before bit 512*b, data words 8*b .. 8*b+7 }.
+static constexpr uint32_t kRankBlockWords = 8; // 512 bits
+
+// pass 1: ones per 512-bit block.  pass 3 (after the scan of `ones`): write the interleaved records.
+__global__ __launch_bounds__(256) void rank_block_ones_kernel(const uint64_t* bits, uint64_t n_words, uint64_t n_blocks,
+                                                              uint64_t* ones)
+{
+	for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t c = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < kRankBlockWords; ++j) {
+			const uint64_t w = b * kRankBlockWords + j;
+			c += w < n_words ? (uint32_t)__popcll(bits[w]) : 0;
+		}
+		ones[b] = c;
+	}
+}
+
+// exclusive prefix sum of n values in place, by ONE workgroup: every thread owns a contiguous slice
+__global__ __launch_bounds__(1024) void scan_u64_kernel(uint64_t* v, uint64_t n, uint64_t* total)
+{
+	__shared__ uint64_t part[1024];
+	const uint64_t per = (n + 1023) / 1024;
+	const uint64_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+	uint64_t sum = 0;
+	for (uint64_t i = lo; i < hi; ++i)
+		sum += v[i];
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint64_t run = 0;
+		for (int t = 0; t < 1024; ++t) {
+			const uint64_t x = part[t];
+			part[t] = run;
+			run += x;
+		}
+		if (total)
+			*total = run;
+	}
+	__syncthreads();
+	uint64_t run = part[threadIdx.x];
+	for (uint64_t i = lo; i < hi; ++i) {
+		const uint64_t x = v[i];
+		v[i] = run;
+		run += x;
+	}
+}
+
+// two-level: chunk sums (4096 blocks a chunk) -> scan of the chunk sums -> per-chunk exclusive scan
+__global__ __launch_bounds__(256) void rank_chunk_sum_kernel(const uint64_t* ones, uint64_t n_blocks, uint64_t* chunk)
+{
+	__shared__ unsigned long long acc;
+	if (threadIdx.x == 0)
+		acc = 0;
+	__syncthreads();
+	unsigned long long c = 0;
+	for (uint32_t j = threadIdx.x; j < 4096; j += 256) {
+		const uint64_t b = (uint64_t)blockIdx.x * 4096 + j;
+		c += b < n_blocks ? ones[b] : 0;
+	}
+	for (int o = 32; o > 0; o >>= 1)
+		c += __shfl_xor(c, o, 64);
+	if ((threadIdx.x & 63) == 0)
+		atomicAdd(&acc, c);
+	__syncthreads();
+	if (threadIdx.x == 0)
+		chunk[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void rank_write_kernel(const uint64_t* bits, uint64_t n_words, uint64_t n_blocks,
+                                                         const uint64_t* ones, const uint64_t* chunk_base, uint64_t* il)
+{
+	// one workgroup per chunk of 4096 blocks; thread t scans blocks [16t, 16t+16) after a workgroup scan
+	__shared__ uint64_t part[256];
+	const uint64_t b0 = (uint64_t)blockIdx.x * 4096 + threadIdx.x * 16;
+	uint64_t mine[16], sum = 0;
+#pragma unroll
+	for (int j = 0; j < 16; ++j) {
+		mine[j] = b0 + j < n_blocks ? ones[b0 + j] : 0;
+		sum += mine[j];
+	}
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint64_t run = chunk_base[blockIdx.x];
+		for (int t = 0; t < 256; ++t) {
+			const uint64_t x = part[t];
+			part[t] = run;
+			run += x;
+		}
+	}
+	__syncthreads();
+	uint64_t run = part[threadIdx.x];
+	for (int j = 0; j < 16; ++j) {
+		const uint64_t b = b0 + j;
+		if (b >= n_blocks)
+			break;
+		uint64_t* rec = il + b * (kRankBlockWords + 1);
+		rec[0] = run;
+		for (uint32_t q = 0; q < kRankBlockWords; ++q) {
+			const uint64_t w = b * kRankBlockWords + q;
+			rec[1 + q] = w < n_words ? bits[w] : 0;
+		}
+		run += mine[j];
+	}
+}
+
+// rank_out[i] = set bits before position pos(i); bit_out[i] = the bit itself.  pos(i) = in[i] % size when `size`
+// is given (in = hash values: getRankPos, MIBloomFilter.hpp:527), else in[i]
+__global__ __launch_bounds__(256) void rank_query_kernel(const uint64_t* il, uint64_t n_bits, const uint64_t* in, uint64_t n,
+                                                         const ModParams mod, int reduce, uint64_t* rank_out,
+                                                         uint8_t* bit_out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t p = in[i];
+		if (reduce)
+			p = mod.pow2 ? (p & mod.mask) : reduce_mod<false>(p, mod);
+		uint64_t r = 0;
+		uint32_t bit = 0;
+		if (p < n_bits) {
+			const uint64_t* rec = il + (p >> 9) * (kRankBlockWords + 1);
+			const uint32_t wq = (uint32_t)(p >> 6) & 7, sh = (uint32_t)p & 63;
+			r = rec[0];
+			for (uint32_t q = 0; q < wq; ++q)
+				r += __popcll(rec[1 + q]);
+			const uint64_t w = rec[1 + wq];
+			r += __popcll(w & ((1ull << sh) - 1));
+			bit = (uint32_t)(w >> sh) & 1u;
+		}
+		if (rank_out)
+			rank_out[i] = r;
+		if (bit_out)
+			bit_out[i] = (uint8_t)bit;
+	}
+}
+
+// scratch: n_blocks + ceil(n_blocks / 4096) + 1 uint64_t
+hipError_t launch_rank_build(const uint64_t* bits, uint64_t n_bits, uint64_t* il, uint64_t* scratch, uint64_t* total_dev,
+                             hipStream_t s)
+{
+	const uint64_t n_words = (n_bits + 63) / 64, n_blocks = (n_bits + 511) / 512;
+	if (n_blocks == 0)
+		return hipSuccess;
+	const uint64_t n_chunks = (n_blocks + 4095) / 4096;
+	if (n_chunks > (1ull << 31))
+		return hipErrorInvalidValue;
+	uint64_t* ones = scratch;
+	uint64_t* chunk = scratch + n_blocks;
+	uint64_t g = (n_blocks + 255) / 256;
+	if (g > 65536)
+		g = 65536;
+	hipLaunchKernelGGL(rank_block_ones_kernel, dim3((unsigned)g), dim3(256), 0, s, bits, n_words, n_blocks, ones);
+	hipLaunchKernelGGL(rank_chunk_sum_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, ones, n_blocks, chunk);
+	hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, s, chunk, n_chunks, total_dev);
+	hipLaunchKernelGGL(rank_write_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, bits, n_words, n_blocks, ones, chunk, il);
+	return hipGetLastError();
+}
+
+hipError_t launch_rank_query(const uint64_t* il, uint64_t n_bits, const uint64_t* in, uint64_t n, const ModParams& mod,
+                             int reduce, uint64_t* rank_out, uint8_t* bit_out, hipStream_t s)
+{
+	if (n == 0)
+		return hipSuccess;
+	uint64_t g = (n + 255) / 256;
+	if (g > 65536)
+		g = 65536;
+	hipLaunchKernelGGL(rank_query_kernel, dim3((unsigned)g), dim3(256), 0, s, il, n_bits, in, n, mod, reduce, rank_out, bit_out);
+	return hipGetLastError();
+}
+
 } // namespace btlbf

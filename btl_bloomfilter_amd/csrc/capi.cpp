@@ -2294,6 +2294,105 @@ extern "C" int btlbf_compare(btlbf_filter* a, btlbf_filter* b, uint64_t* out3)
 }
 
 // -------------------------------------------------------------------------------------------------
+// rank structure (miBF stage 2)
+// -------------------------------------------------------------------------------------------------
+struct btlbf_rank {
+	int device = 0;
+	uint64_t n_bits = 0, n_blocks = 0, ones = 0;
+	ModParams mod{};
+	uint64_t* d_il = nullptr; // n_blocks records of 9 uint64_t
+};
+
+extern "C" int btlbf_rank_create(btlbf_rank** out, btlbf_filter* f)
+{
+	if (!out || !f)
+		return fail(BTLBF_EINVAL, "null argument");
+	*out = nullptr;
+	if (f->kind != BTLBF_BLOOM || f->shard_count != 1)
+		return fail(BTLBF_EINVAL, "rank structure: needs a whole bit filter");
+	FilterLock lk__(f);
+	DeviceGuard g(f->device);
+	HIP_TRY(hipDeviceSynchronize());
+	btlbf_rank* r = new btlbf_rank();
+	r->device = f->device;
+	r->n_bits = f->size;
+	r->n_blocks = (f->size + 511) / 512;
+	fill_mod(r->mod, f->size, 0, f->size);
+	DevBuf scratch;
+	hipError_t e = hipMalloc((void**)&r->d_il, r->n_blocks * 9 * 8 + 16);
+	if (e == hipSuccess)
+		e = scratch.alloc((r->n_blocks + (r->n_blocks + 4095) / 4096 + 2) * 8);
+	if (e != hipSuccess) {
+		(void)hipFree(r->d_il);
+		delete r;
+		(void)hipGetLastError();
+		return fail(BTLBF_ENOMEM, "rank structure: %llu bytes of HBM", (unsigned long long)(r->n_blocks * 72));
+	}
+	uint64_t* total = scratch.as<uint64_t>() + r->n_blocks + (r->n_blocks + 4095) / 4096;
+	e = launch_rank_build(static_cast<const uint64_t*>(f->d_data), f->size, r->d_il, scratch.as<uint64_t>(), total, nullptr);
+	if (e == hipSuccess)
+		e = hipMemcpy(&r->ones, total, 8, hipMemcpyDeviceToHost);
+	if (e != hipSuccess) {
+		(void)hipFree(r->d_il);
+		delete r;
+		return fail(BTLBF_EHIP, "rank structure: %s", hipGetErrorString(e));
+	}
+	*out = r;
+	return BTLBF_OK;
+}
+
+extern "C" void btlbf_rank_destroy(btlbf_rank* r)
+{
+	if (!r)
+		return;
+	DeviceGuard g(r->device);
+	(void)hipFree(r->d_il);
+	delete r;
+}
+
+extern "C" uint64_t btlbf_rank_ones(const btlbf_rank* r) { return r ? r->ones : 0; }
+extern "C" uint64_t btlbf_rank_words(const btlbf_rank* r) { return r ? r->n_blocks * 9 : 0; }
+
+extern "C" int btlbf_rank_download(const btlbf_rank* r, uint64_t* host_dst)
+{
+	if (!r || !host_dst)
+		return fail(BTLBF_EINVAL, "null argument");
+	DeviceGuard g(r->device);
+	HIP_TRY(hipMemcpy(host_dst, r->d_il, r->n_blocks * 72, hipMemcpyDeviceToHost));
+	return BTLBF_OK;
+}
+
+extern "C" int btlbf_rank_query(const btlbf_rank* r, const uint64_t* values, uint64_t n, int values_are_hashes,
+                                uint64_t* rank_out, uint8_t* bit_out, int mem, void* stream)
+{
+	if (!r || (n && !values))
+		return fail(BTLBF_EINVAL, "null argument");
+	if (mem != BTLBF_HOST && mem != BTLBF_DEVICE)
+		return fail(BTLBF_EINVAL, "mem must be BTLBF_HOST or BTLBF_DEVICE");
+	DeviceGuard g(r->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	DevBuf din;
+	const uint64_t* dv = values;
+	if (mem == BTLBF_HOST) {
+		HIP_TRY(din.alloc(n * 8));
+		if (n)
+			HIP_TRY(hipMemcpyAsync(din.p, values, n * 8, hipMemcpyHostToDevice, s));
+		dv = din.as<uint64_t>();
+	}
+	OutBuf o_rank, o_bit;
+	int rc;
+	if ((rc = o_rank.prepare(rank_out, n * 8, mem, false, s)) || (rc = o_bit.prepare(bit_out, n, mem, false, s)))
+		return rc;
+	HIP_TRY(launch_rank_query(r->d_il, r->n_bits, dv, n, r->mod, values_are_hashes, static_cast<uint64_t*>(o_rank.d),
+	                          static_cast<uint8_t*>(o_bit.d), s));
+	if ((rc = o_rank.finish(s)) || (rc = o_bit.finish(s)))
+		return rc;
+	if (mem == BTLBF_HOST)
+		HIP_TRY(hipStreamSynchronize(s));
+	return BTLBF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
 // multi-GPU helpers
 // -------------------------------------------------------------------------------------------------
 extern "C" int btlbf_positions_seqs(btlbf_filter* f, const char* seq, uint64_t len,

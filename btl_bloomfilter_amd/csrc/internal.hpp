@@ -220,6 +220,12 @@ hipError_t launch_merge_split_bitmaps(uint64_t len, uint32_t L, const uint64_t* 
                                       const uint64_t* warm_hit, const uint64_t* cold_hit, const uint64_t* warm_valid,
                                       const uint64_t* cold_valid, uint64_t* hit_out, uint64_t* valid_out, hipStream_t s);
 
+// rank structure over a bit filter (aux_kernels.hip): interleaved 512-bit blocks + rank queries
+hipError_t launch_rank_build(const uint64_t* bits, uint64_t n_bits, uint64_t* il, uint64_t* scratch, uint64_t* total_dev,
+                             hipStream_t s);
+hipError_t launch_rank_query(const uint64_t* il, uint64_t n_bits, const uint64_t* in, uint64_t n, const ModParams& mod,
+                             int reduce, uint64_t* rank_out, uint8_t* bit_out, hipStream_t s);
+
 int seq_tile_windows(); // windows per workgroup tile (for host-side sizing)
 
 } // namespace btlbf

@@ -455,6 +455,46 @@ class CountingBloomFilter(_Filter):
         return mn[:n], valid
 
 
+class RankSupport:
+    """sdsl::bit_vector_il<512> + rank_support_il<1> over a bit filter, in HBM (btlbf_rank_*): what the
+    reference's miBF uses to turn a set bit into an index of its ID array (MIBloomFilter.hpp:527,801-803)"""
+
+    def __init__(self, bloom):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.btlbf_rank_create(C.byref(h), bloom._h))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.btlbf_rank_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ones(self):
+        return self._L.btlbf_rank_ones(self._h)
+
+    def interleaved(self):
+        """the interleaved vector as (n_blocks, 9) uint64: column 0 = set bits before the block"""
+        out = np.zeros(self._L.btlbf_rank_words(self._h), np.uint64)
+        check(self._L.btlbf_rank_download(self._h, C.c_void_p(out.ctypes.data)))
+        return out.reshape(-1, 9)
+
+    def rank(self, values, hashes=False):
+        """(rank, bit) of positions, or of hash values reduced modulo the filter size (getRankPos)"""
+        v = np.ascontiguousarray(values, np.uint64).ravel()
+        r = np.zeros(max(v.size, 1), np.uint64)
+        b = np.zeros(max(v.size, 1), np.uint8)
+        check(self._L.btlbf_rank_query(self._h, C.c_void_p(v.ctypes.data), v.size, int(bool(hashes)),
+                                       C.c_void_p(r.ctypes.data), C.c_void_p(b.ctypes.data), HOST, None))
+        return r[: v.size], b[: v.size]
+
+
 def _hash_seqs(seq, k, h, seeds, h2, starts, read_len, device, stream):
     L = _lib.load()
     b = _Buf(seq)

@@ -229,6 +229,26 @@ int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out);
  * differ, counters with a > b, counters with a < b}.  Synchronises the device. */
 int btlbf_compare(btlbf_filter* a, btlbf_filter* b, uint64_t* out3);
 
+/* ---- rank structure over a bit filter (miBF stage 2) ------------------------------------
+ * The reference's multi-index Bloom filter maps a set bit to an index of its ID array with
+ * rank(pos) = set bits before pos -- getRankPos(hash) = m_rankSupport(hash % m_bv.size()), MIBloomFilter.hpp:527,
+ * and the same expression in every insert / query loop (:324,391,443,461,488,509,522) -- over
+ * sdsl::bit_vector_il<512> + sdsl::rank_support_il<1> (MIBloomFilter.hpp:44,133,144,801-803; sdsl-lite is an
+ * un-vendored dependency of the reference).  rank_create builds that interleaved vector in HBM from a bit
+ * filter (e.g. the spaced-seed filter that is miBF stage 1, MIBFConstructSupport.hpp:75-87): record b of 9
+ * uint64_t = { set bits before bit 512*b, the 8 data words of block b }.  rank_query: values are positions,
+ * or hash values to be reduced modulo the filter size (values_are_hashes != 0); rank_out[i] = rank,
+ * bit_out[i] = the bit itself (either may be NULL).  rank_ones = set bits in total (= entries of the ID
+ * array, MIBloomFilter.hpp:573-577); rank_download copies the rank_words() interleaved words to the host. */
+typedef struct btlbf_rank btlbf_rank;
+int btlbf_rank_create(btlbf_rank** out, btlbf_filter* f);
+void btlbf_rank_destroy(btlbf_rank* r);
+uint64_t btlbf_rank_ones(const btlbf_rank* r);
+uint64_t btlbf_rank_words(const btlbf_rank* r);
+int btlbf_rank_download(const btlbf_rank* r, uint64_t* host_dst);
+int btlbf_rank_query(const btlbf_rank* r, const uint64_t* values, uint64_t n, int values_are_hashes,
+                     uint64_t* rank_out, uint8_t* bit_out, int mem, void* stream);
+
 /* ---- multi-GPU hash-range sharding ------------------------------------------------
  * The M-bit filter is cut into n_shards contiguous bit ranges; shard g (btlbf_create_shard) holds
  * positions [g*M/n, (g+1)*M/n).  Routing is by POSITION, so the concatenated shard bodies are the

@@ -90,6 +90,17 @@ def main():
             # k % 4 == 0: the reference's tetramer path shifts a uint64_t by 64 (rolx/swapxbits033 with
             # remainder 0, nthash.hpp:354-356,388-391,404-406) -- undefined behaviour; recorded but flagged
             gk.append(dict(kmer=kmer, k=k, h=4, hashes=hx(ref.kmer_hashes(kmer, k, 4)), ub=(k % 4 == 0)))
+    # k-mers containing U / u: the reference's raw-k-mer path maps U to A (its 2/3/4-mer tables index with
+    # convertTab, nthash.hpp:16-86) while its iterator path hashes U like T (seedTab, nthash.hpp:195-228) -- the
+    # two paths of the reference disagree with each other; what g++/x86 returns is recorded and flagged
+    rng_u = np.random.RandomState(77)  # its own generator: the fixtures that follow keep their random inputs
+    for k in (5, 7, 25, 31, 33):
+        for t in range(2):
+            km = list(rand_seq(rng_u, k))
+            for j in rng_u.choice(k, 2, replace=False):
+                km[j] = "Uu"[t]
+            kmer = "".join(km)
+            gk.append(dict(kmer=kmer, k=k, h=4, hashes=hx(ref.kmer_hashes(kmer, k, 4)), ub=False, u=True))
     json.dump(dict(nthash=g1, sthash=g2, kmer=gk), open(os.path.join(HERE, "hash_vectors.json"), "w"))
 
     # ---------------- G3: tiny .bf files (whole-file bytes) ----------------
