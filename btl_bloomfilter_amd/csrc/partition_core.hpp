@@ -148,15 +148,14 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	__syncthreads();
 	STAMP(4);
 	{
-		// bins are owned by lanes (P <= NT), spread evenly over the waves: wave v owns bins [v*bpw, (v+1)*bpw),
-		// bpw = ceil(P / waves) <= 64, and flushes them itself through its private slice of the flush list --
-		// no workgroup barrier in between (with 512 bins every one of the 16 waves flushes 32 bins, instead
-		// of eight waves flushing 64 each while the other eight wait at the barrier)
-		const uint32_t lane = tid & 63;
-		const uint32_t bpw = (P + NT / 64 - 1) / (NT / 64);
-		const uint32_t b = (tid >> 6) * bpw + lane;
+		// bins are owned by lanes (P <= NT): wave v owns bins [64v, 64v+64) and flushes them itself,
+		// through its private slice of the flush list -- no workgroup barrier in between.  (Spreading 512
+		// bins over all 16 waves, 32 each, was measured: the same time and 5 % more instructions, because
+		// the waves without bins skip this block outright.)
+		const uint32_t b = tid, lane = tid & 63;
+		constexpr uint32_t bpw = 64;
 		uint32_t nfl = 0, rd0 = 0, w0 = 0;
-		if (lane < bpw && b < P) {
+		if (b < P) {
 			const uint32_t w = l.pt[b];
 			const uint32_t occ = w & 0xffffu;           // ring content + everything offered this round
 			const uint32_t avail = occ < SC ? occ : SC; // entries that really sit in the ring

@@ -17,6 +17,8 @@ import time
 import numpy as np
 import torch
 
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import btl_bloomfilter_amd as m
 
 

@@ -8,6 +8,8 @@ import time
 import numpy as np
 import torch
 
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import btl_bloomfilter_amd as m
 
 
@@ -52,8 +54,13 @@ def one_case(rng, it):
     thr = int(rng.integers(1, 4))
     q = flat.clone()
     q[torch.from_numpy(rng.integers(0, q.numel(), max(1, q.numel() // 5000))).cuda()] = ord("A")
+    if not ragged and rng.random() < 0.5:  # foreign reads among the inserted ones: AUTO may split the query
+        frac = float(rng.choice([0.02, 0.1, 0.5, 0.9]))
+        idx = np.flatnonzero(rng.random(n_reads) < frac)
+        if idx.size:
+            q.view(n_reads, L)[torch.from_numpy(idx).cuda()] = torch.from_numpy(rand_reads(rng, idx.size, L, 0.001)).cuda()
     res = []
-    for mode in ("direct", "partitioned"):
+    for mode in ("direct", "partitioned", "auto"):
         if counting:
             f = m.CountingBloomFilter(max(bits // 8, 64), h, k, thr)
         else:
@@ -73,13 +80,14 @@ def one_case(rng, it):
         res.append((f.download().copy(), hit.cpu().numpy().copy(), cnt.tolist(), thr, valid.cpu().numpy().copy()))
         f.releaseScratch()
         del f
-    a, b = res
-    same = [bool((a[0] == b[0]).all()), bool((a[1] == b[1]).all()), a[2] == b[2], bool((a[4] == b[4]).all())]
+    a, b, c = res
+    same = [bool((a[0] == b[0]).all()), bool((a[1] == b[1]).all()), a[2] == b[2], bool((a[4] == b[4]).all()),
+            bool((a[0] == c[0]).all()), bool((a[1] == c[1]).all()), a[2] == c[2], bool((a[4] == c[4]).all())]
     ok = all(same)
     desc = dict(it=it, bits=bits, k=k, h=h, L=L, n_reads=n_reads, counting=bool(counting), ragged=bool(ragged), scratch=scratch,
                 spaced=bool(seeds))
     if not ok:
-        print("MISMATCH (filter, hits, counts, valid) =", same, desc, a[2], b[2], flush=True)
+        print("MISMATCH (filter, hits, counts, valid) x (partitioned, auto) =", same, desc, a[2], b[2], c[2], flush=True)
     return ok, desc
 
 
