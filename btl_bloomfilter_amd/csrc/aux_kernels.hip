@@ -478,8 +478,10 @@ __global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, ui
                                                           unsigned long long* flags, unsigned long long* n_cold)
 {
 	__shared__ uint64_t tab[kNumCodes][2]; // Horner start-up seeds per base code (HashParams::init_tab)
+	__shared__ uint8_t lut[256];           // byte -> code << 4 | flags (base_entry)
 	if (threadIdx.x < kNumCodes * 2)
 		tab[threadIdx.x >> 1][threadIdx.x & 1] = hp.init_tab[threadIdx.x >> 1][threadIdx.x & 1];
+	lut[threadIdx.x] = base_entry(threadIdx.x); // 256 threads
 	__syncthreads();
 	const uint64_t i_s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	// stride > 1: a pseudo-random read of every block of `stride` reads, so that input with a period (every
@@ -501,16 +503,24 @@ __global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, ui
 			for (; i + 4 <= k; i += 4) { // four bases per (unaligned) load
 				uint32_t word;
 				__builtin_memcpy(&word, w + i, 4);
+				// ACGT/acgt in one step (the byte permute of seq_stage_convert), anything else through the LUT
+				const uint32_t idx = (word >> 1) & 0x03030303u;
+				uint32_t e4;
+				if ((word & 0xdfdfdfdfu) == __builtin_amdgcn_perm(0u, 0x47544341u, idx))
+					e4 = __builtin_amdgcn_perm(0u, 0x23331303u, idx);
+				else
+					e4 = (uint32_t)lut[word & 0xff] | ((uint32_t)lut[(word >> 8) & 0xff] << 8) |
+					     ((uint32_t)lut[(word >> 16) & 0xff] << 16) | ((uint32_t)lut[word >> 24] << 24);
 #pragma unroll
 				for (int b = 0; b < 4; ++b) {
-					const uint32_t e = base_entry((word >> (8 * b)) & 0xff);
+					const uint32_t e = (e4 >> (8 * b)) & 0xff;
 					ok &= e;
 					fh = srol1(fh) ^ tab[e >> kCodeShift][0];
 					rh = sror1(rh) ^ tab[e >> kCodeShift][1];
 				}
 			}
 			for (; i < k; ++i) {
-				const uint32_t e = base_entry(w[i]);
+				const uint32_t e = lut[w[i]];
 				ok &= e;
 				fh = srol1(fh) ^ tab[e >> kCodeShift][0];
 				rh = sror1(rh) ^ tab[e >> kCodeShift][1];
@@ -596,31 +606,41 @@ __device__ __forceinline__ uint32_t cold_rank(const unsigned long long* flags, c
 	return prefix[r >> 6] + (uint32_t)__popcll(m & ((1ull << (r & 63)) - 1));
 }
 
-// one wave per 8 reads: read r goes to cold_buf[rank * L] or warm_buf[(r - rank) * L]
-__global__ __launch_bounds__(256) void compact_reads_kernel(const uint8_t* seq, uint64_t n_reads, uint32_t L,
+// one thread per 16 source bytes (coalesced 16-byte loads when the buffer is 16-byte aligned): the bytes of
+// read r go to cold_buf[rank * L + ...] or warm_buf[(r - rank) * L + ...]; a 16-byte piece lies in one read or
+// straddles a boundary (several, if reads are shorter than 16 bytes)
+__global__ __launch_bounds__(256) void compact_reads_kernel(const uint8_t* seq, uint64_t len, uint32_t L,
                                                             const unsigned long long* flags, const uint32_t* prefix,
                                                             uint8_t* warm_buf, uint8_t* cold_buf)
 {
-	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const uint32_t lane = threadIdx.x & 63;
-	for (uint32_t q = 0; q < 8; ++q) {
-		const uint64_t r = wave * 8 + q;
-		if (r >= n_reads)
-			return;
+	const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+	if (p0 >= len)
+		return;
+	const uint32_t n = len - p0 < 16 ? (uint32_t)(len - p0) : 16;
+	uint64_t r = p0 / L;
+	uint32_t off = (uint32_t)(p0 - r * L);
+	if (n == 16 && off + 16 <= L && ((reinterpret_cast<uintptr_t>(seq) + p0) & 15) == 0) {
+		// the common case: the whole piece inside one read -- registers only
+		const uint4 q = *reinterpret_cast<const uint4*>(seq + p0);
 		bool cold;
 		const uint32_t rk = cold_rank(flags, prefix, r, &cold);
-		const uint8_t* src = seq + r * L;
-		uint8_t* dst = cold ? cold_buf + (uint64_t)rk * L : warm_buf + (r - rk) * L;
-		for (uint32_t o = lane * 4; o < L; o += 256) {
-			if (o + 4 <= L) {
-				uint32_t v;
-				__builtin_memcpy(&v, src + o, 4);
-				__builtin_memcpy(dst + o, &v, 4);
-			} else {
-				for (uint32_t b = o; b < L; ++b)
-					dst[b] = src[b];
-			}
-		}
+		uint8_t* dst = (cold ? cold_buf + (uint64_t)rk * L : warm_buf + (r - rk) * L) + off;
+		__builtin_memcpy(dst, &q.x, 4); // unaligned dword stores
+		__builtin_memcpy(dst + 4, &q.y, 4);
+		__builtin_memcpy(dst + 8, &q.z, 4);
+		__builtin_memcpy(dst + 12, &q.w, 4);
+		return;
+	}
+	for (uint32_t i = 0; i < n;) { // a piece that straddles a read boundary (or the tail): byte by byte
+		bool cold;
+		const uint32_t rk = cold_rank(flags, prefix, r, &cold);
+		uint8_t* dst = (cold ? cold_buf + (uint64_t)rk * L : warm_buf + (r - rk) * L) + off;
+		const uint32_t m = (L - off) < (n - i) ? (L - off) : (n - i);
+		for (uint32_t j = 0; j < m; ++j)
+			dst[j] = seq[p0 + i + j];
+		i += m;
+		off = 0;
+		++r;
 	}
 }
 
@@ -704,8 +724,8 @@ hipError_t launch_compact_reads(const uint8_t* seq, uint64_t n_reads, uint32_t L
 {
 	if (n_reads == 0)
 		return hipSuccess;
-	const uint64_t waves = (n_reads + 7) / 8;
-	hipLaunchKernelGGL(compact_reads_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, seq, n_reads, L,
+	const uint64_t len = n_reads * L, pieces = (len + 15) / 16;
+	hipLaunchKernelGGL(compact_reads_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, seq, len, L,
 	                   reinterpret_cast<const unsigned long long*>(flags), prefix, warm_buf, cold_buf);
 	return hipGetLastError();
 }

@@ -1514,6 +1514,10 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 {
 	*decided = 0;
 	const uint32_t L = a.layout.starts ? 0 : a.layout.read_len, k = f->hp.k;
+	// whole filters only: the sampler probes f->d_data with positions of the whole array (a shard answers for its
+	// window through the WINDOW kernels; want_partitioned_query decides for it)
+	if (f->shard_count != 1 || f->mod.shard_lo != 0 || f->mod.shard_len != f->mod.size)
+		return BTLBF_OK;
 	if (f->query_mode != BTLBF_INSERT_AUTO || !L || L < k || L < 8 || f->hp.n_seeds || !part_supported_h(f->hp.h))
 		return BTLBF_OK;
 	const uint64_t n_reads = a.len / L;

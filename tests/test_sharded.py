@@ -318,6 +318,21 @@ def test_sharded_counting_filter_two_ranks_one_gpu(tmp_path, mode, world):
         assert (n_reads // 2) * (L - k + 1) <= cnt[1] < cnt[0]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["exchange", "gather"])
+def test_sharded_counting_filter_golden_digest(tmp_path, mode):
+    """the sharded counting filter against the REFERENCE's own counters: golden fixture cbf_medium_all (2^27
+    uint8_t counters, k=25, h=3, 200 000 reads through incrementAll and the first 100 000 a second time) built by
+    two shards, routed and gathered; rank 1 has nothing to insert in the second pass and takes part empty-handed"""
+    g = load_golden("digests.json")["cbf_medium_all"]
+    world = 2
+    mp.spawn(gpu_worker_counting, args=(world, free_port(), str(tmp_path), g["bytes"], g["h"], g["k"], g["thr"],
+                                        g["n_reads"] // world, g["read_len"], mode, "golden"), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("body%d.npy" % r)) for r in range(world)])
+    assert got.size == g["bytes"] and sha(got) == g["body_sha256"]
+    assert int((got != 0).sum()) == g["popcount"] and int((got >= g["thr"]).sum()) == g["filtered_popcount"]
+
+
 def _nccl_one_rank_worker(rank, port, outdir, mode, shard_mode="exchange"):
     import btl_bloomfilter_amd as m
     from btl_bloomfilter_amd.sharded import ShardedBloomFilter
