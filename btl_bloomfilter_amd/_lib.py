@@ -51,6 +51,9 @@ _PROTOS = {
                                      C.c_uint, C.c_uint, C.c_int]),
     "btlbf_destroy": (C.c_int, [_P]),
     "btlbf_load": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_uint, C.c_int]),
+    "btlbf_create_from_header": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_size_t, C.c_uint, C.c_int]),
+    "btlbf_get_dfpr": (C.c_double, [_P]),
+    "btlbf_set_dfpr": (None, [_P, C.c_double]),
     "btlbf_store": (C.c_int, [_P, C.c_char_p]),
     "btlbf_header": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "btlbf_store_shard": (C.c_int, [_P, C.c_char_p]),

@@ -845,6 +845,49 @@ extern "C" int btlbf_load(btlbf_filter** out, int kind, const char* path, unsign
 	return BTLBF_OK;
 }
 
+// A zeroed filter with the geometry and the bookkeeping fields of a header text (everything up to and including
+// the "[HeaderEnd]" line): what the reference's public loadHeader(std::istream&) leaves behind
+// (BloomFilter.hpp:118-166, CountingBloomFilter.hpp:84,282-343) before loadFilter reads the body.
+extern "C" int btlbf_create_from_header(btlbf_filter** out, int kind, const char* header, size_t len, unsigned threshold,
+                                        int device)
+{
+	if (!out || !header)
+		return fail(BTLBF_EINVAL, "null argument");
+	*out = nullptr;
+	FILE* fp = fmemopen(const_cast<char*>(header), len, "rb");
+	if (!fp)
+		return fail(BTLBF_EIO, "fmemopen: %s", strerror(errno));
+	ParsedHeader ph;
+	int rc = parse_header(fp, kind, "<header>", ph);
+	fclose(fp);
+	if (rc)
+		return rc;
+	btlbf_filter* f = nullptr;
+	if (kind == BTLBF_BLOOM) {
+		if (ph.size % 8 != 0)
+			return fail(BTLBF_EINVAL, "ERROR: Filter Size \"%llu\" is not a multiple of 8.", (unsigned long long)ph.size);
+		rc = make_filter(&f, kind, ph.size, ph.size / 8, 0, 1, ph.h, ph.k, 0, device);
+	} else {
+		if (ph.bits_per_counter != 8 || ph.size != ph.size_bytes)
+			return fail(BTLBF_EFORMAT, "only 8-bit counters are supported (BitsPerCounter = %u)", ph.bits_per_counter);
+		rc = make_filter(&f, kind, ph.size, ph.size_bytes, 0, 1, ph.h, ph.k, threshold, device);
+	}
+	if (rc)
+		return rc;
+	f->dfpr = ph.dfpr;
+	f->n_entry = ph.n_entry;
+	f->t_entry = ph.t_entry;
+	*out = f;
+	return BTLBF_OK;
+}
+
+extern "C" double btlbf_get_dfpr(const btlbf_filter* f) { return f ? f->dfpr : 0.0; }
+extern "C" void btlbf_set_dfpr(btlbf_filter* f, double v)
+{
+	if (f)
+		f->dfpr = v;
+}
+
 static int write_body(const btlbf_filter* f, int fd, uint64_t file_off, const char* path)
 {
 	const size_t chunk = 64u << 20;

@@ -103,6 +103,11 @@ int btlbf_destroy(btlbf_filter* f); /* ~BloomFilter, BloomFilter.hpp:381 */
  * store: storeFilter BloomFilter.hpp:304-314 / CountingBloomFilter.hpp:331-342; the header bytes
  *        are those the reference writes (key order, tab indent, %#.17g doubles) */
 int btlbf_load(btlbf_filter** out, int kind, const char* path, unsigned threshold, int device);
+/* header text only (everything up to and including the "[HeaderEnd]" line) -> a zeroed filter of that geometry
+ * with nEntry / Entry / dFPR taken over: what the reference's public loadHeader(std::istream&) leaves behind
+ * (BloomFilter.hpp:118-166, CountingBloomFilter.hpp:84,282-343); the caller fills the body (btlbf_upload) */
+int btlbf_create_from_header(btlbf_filter** out, int kind, const char* header, size_t len, unsigned threshold,
+                             int device);
 int btlbf_store(btlbf_filter* f, const char* path);
 /* header text only (writeHeader BloomFilter.hpp:264-288, storeHeader CountingBloomFilter.hpp:344-368) */
 int btlbf_header(const btlbf_filter* f, char* buf, size_t cap, size_t* len);
@@ -122,6 +127,8 @@ uint64_t btlbf_get_n_entry(const btlbf_filter* f);
 uint64_t btlbf_get_t_entry(const btlbf_filter* f);
 void btlbf_set_n_entry(btlbf_filter* f, uint64_t v); /* setnEntry BloomFilter.hpp:373 */
 void btlbf_set_t_entry(btlbf_filter* f, uint64_t v); /* settEntry BloomFilter.hpp:375 */
+double btlbf_get_dfpr(const btlbf_filter* f);         /* m_dFPR: the header's dFPR field (BloomFilter.hpp:83-99,277) */
+void btlbf_set_dfpr(btlbf_filter* f, double v);
 void* btlbf_device_ptr(const btlbf_filter* f);       /* the HBM array */
 int btlbf_device(const btlbf_filter* f);
 

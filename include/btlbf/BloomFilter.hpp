@@ -40,6 +40,25 @@ class BloomFilter
 		                               btlbf_shim::default_device()));
 	}
 
+	// BloomFilter(size_t expectedElemNum, double fpr, unsigned hashNum, unsigned kmerSize), BloomFilter.hpp:83-99:
+	// sized from the expected number of elements and the target FPR (hashNum 0 = the optimum for that FPR).
+	// The reference's own version frees an uninitialised pointer on this path; the
+	// arithmetic is the reference's (calcOptiHashNum :419, calcOptimalSize :406-413) and dFPR lands in the header.
+	BloomFilter(size_t expectedElemNum, double fpr, unsigned hashNum, unsigned kmerSize)
+	{
+		const unsigned h = hashNum ? hashNum : calcOptiHashNum(fpr);
+		btlbf_shim::check(btlbf_create(&m_f, BTLBF_BLOOM, calcOptimalSize(expectedElemNum, fpr, h), h, kmerSize, 0,
+		                               btlbf_shim::default_device()));
+		btlbf_set_dfpr(m_f, fpr);
+	}
+	static unsigned calcOptiHashNum(double fpr) { return unsigned(-std::log(fpr) / std::log(2)); }
+	// only multiples of 64 (BloomFilter.hpp:401-413)
+	static size_t calcOptimalSize(size_t entries, double fpr, unsigned hashNum)
+	{
+		const size_t v = size_t(-double(entries) * double(hashNum) / std::log(1.0 - std::pow(fpr, 1.0 / double(hashNum))));
+		return v + (64 - v % 64);
+	}
+
 	// BloomFilter(const string& filterFilePath), BloomFilter.hpp:101-105
 	explicit BloomFilter(const std::string& filterFilePath) { loadFilter(filterFilePath); }
 
@@ -54,6 +73,46 @@ class BloomFilter
 		btlbf_shim::check(
 		    btlbf_load(&m_f, BTLBF_BLOOM, filterFilePath.c_str(), 0, btlbf_shim::default_device()));
 	}
+
+	// loadHeader(std::istream&), BloomFilter.hpp:118-166: consumes the header lines up to "[HeaderEnd]" and leaves a
+	// zeroed filter of the header's geometry (nEntry / Entry / dFPR taken over); the stream is then positioned at
+	// the body, which loadBody reads (the reference's loadFilter does the two in turn, :107-116)
+	void loadHeader(std::istream& file)
+	{
+		std::string text, line;
+		bool end = false;
+		while (std::getline(file, line)) {
+			text += line + "\n";
+			if (line == "[HeaderEnd]") {
+				end = true;
+				break;
+			}
+			if (text.size() > (1u << 16))
+				break;
+		}
+		(void)end; // a missing header end is reported by the C ABI in the reference's words
+		btlbf_destroy(m_f);
+		m_f = nullptr;
+		for (auto& st : m_stripes)
+			st.rows.clear();
+		btlbf_shim::check(btlbf_create_from_header(&m_f, BTLBF_BLOOM, text.data(), text.size(), 0,
+		                                           btlbf_shim::default_device()));
+	}
+	void loadBody(std::istream& file)
+	{
+		std::vector<char> chunk(1u << 24);
+		const uint64_t total = sizeInBytes();
+		for (uint64_t off = 0; off < total; off += chunk.size()) {
+			const uint64_t n = std::min<uint64_t>(chunk.size(), total - off);
+			file.read(chunk.data(), (std::streamsize)n);
+			if ((uint64_t)file.gcount() != n) {
+				std::cerr << "error: short read of the filter body" << std::endl;
+				std::exit(EXIT_FAILURE);
+			}
+			btlbf_shim::check(btlbf_upload(m_f, chunk.data(), off, n));
+		}
+	}
+	double getDesiredFPR() const { return btlbf_get_dfpr(m_f); }
 
 	// ---- per-k-mer interface (precomputed hash values, m_hashNum per k-mer) ----
 	void insert(const uint64_t precomputed[]) // BloomFilter.hpp:185-194

@@ -13,7 +13,9 @@
 #define BTLBF_COUNTINGBLOOMFILTER_HPP
 #include "detail.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <istream>
 #include <string>
 #include <vector>
 
@@ -132,6 +134,35 @@ class CountingBloomFilter
 		btlbf_destroy(m_f);
 		m_f = nullptr;
 		btlbf_shim::check(btlbf_load(&m_f, BTLBF_COUNTING8, path.c_str(), m_threshold, btlbf_shim::default_device()));
+	}
+	// loadHeader(std::istream&), CountingBloomFilter.hpp:84,282-330: the header lines up to "[HeaderEnd]" -> a zeroed
+	// filter of that geometry; the stream is left at the body (loadBody)
+	void loadHeader(std::istream& file)
+	{
+		std::string text, line;
+		while (std::getline(file, line)) {
+			text += line + "\n";
+			if (line == "[HeaderEnd]" || text.size() > (1u << 16))
+				break;
+		}
+		btlbf_destroy(m_f);
+		m_f = nullptr;
+		btlbf_shim::check(btlbf_create_from_header(&m_f, BTLBF_COUNTING8, text.data(), text.size(), m_threshold,
+		                                           btlbf_shim::default_device()));
+	}
+	void loadBody(std::istream& file)
+	{
+		std::vector<char> chunk(1u << 24);
+		const uint64_t total = sizeInBytes();
+		for (uint64_t off = 0; off < total; off += chunk.size()) {
+			const uint64_t n = std::min<uint64_t>(chunk.size(), total - off);
+			file.read(chunk.data(), (std::streamsize)n);
+			if ((uint64_t)file.gcount() != n) {
+				std::cerr << "error: short read of the filter body" << std::endl;
+				std::exit(EXIT_FAILURE);
+			}
+			btlbf_shim::check(btlbf_upload(m_f, chunk.data(), off, n));
+		}
 	}
 	void storeFilter(const std::string& path) const // :331-342
 	{

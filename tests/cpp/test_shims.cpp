@@ -257,6 +257,50 @@ static void file_loaders_equal_insert_seq()
 	std::remove(f4.c_str());
 }
 
+// the FPR-sizing constructor (BloomFilter.hpp:83-99; it crashes in the reference) and the public
+// loadHeader(std::istream&) (BloomFilter.hpp:118-166)
+static void sizing_ctor_and_load_header()
+{
+	BloomFilter f(100000, 0.01, 0, 21);
+	CHECK(f.getHashNum() == 6);                      // unsigned(-log(0.01) / log(2))
+	CHECK(f.getFilterSize() % 64 == 0 && f.getFilterSize() == BloomFilter::calcOptimalSize(100000, 0.01, 6));
+	CHECK(f.getDesiredFPR() == 0.01);
+	insertSeq(f, "ACGTTGCATGCATGCAAACCGGTTACGATCGATCGATTAGCTAGCTAGGCTAGCTA", 6, 21);
+	f.setnEntry(36);
+	const std::string fn = tmp_name("sizing");
+	f.storeFilter(fn);
+	const std::string raw = slurp(fn);
+	CHECK(raw.find("\tdFPR = 0.010000000000000000\n") != std::string::npos); // cpptoml: showpoint, 17 significant digits
+	std::ifstream in(fn, std::ios::binary);
+	BloomFilter g;
+	g.loadHeader(in);
+	CHECK(g.getFilterSize() == f.getFilterSize() && g.getHashNum() == 6 && g.getKmerSize() == 21);
+	CHECK(g.getnEntry() == 36 && g.getDesiredFPR() == 0.01 && g.getPop() == 0);
+	g.loadBody(in);
+	CHECK(g.getPop() == f.getPop() && g.getPop() > 0);
+	const std::string fn2 = tmp_name("sizing2");
+	g.storeFilter(fn2);
+	CHECK(slurp(fn2) == raw);
+	std::remove(fn.c_str());
+	std::remove(fn2.c_str());
+	// the counting filter's loadHeader (CountingBloomFilter.hpp:84)
+	CountingBloomFilter<uint8_t> c(4096, 3, 21, 1);
+	ntHashIterator it("ACGTTGCATGCATGCAAACCGGTTACGATCGATCGATTAGC", 3, 21);
+	while (it != it.end()) {
+		c.insert(*it);
+		++it;
+	}
+	const std::string fc = tmp_name("cbfhdr");
+	c.storeFilter(fc);
+	std::ifstream cin2(fc, std::ios::binary);
+	CountingBloomFilter<uint8_t> d2(8, 1, 1, 1);
+	d2.loadHeader(cin2);
+	CHECK(d2.size() == c.size() && d2.getHashNum() == 3 && d2.getKmerSize() == 21 && d2.popCount() == 0);
+	d2.loadBody(cin2);
+	CHECK(d2.popCount() == c.popCount() && d2.popCount() > 0);
+	std::remove(fc.c_str());
+}
+
 // synthetic reads of SURVEY.md 8d (the generator behind tests/golden/digests.json)
 static std::string synth_read(uint64_t seed, uint64_t r, unsigned len)
 {
@@ -346,6 +390,7 @@ int main(int argc, char** argv)
 	counting_basic();
 	fused_path_equals_iterator_path(argc > 1 ? argv[1] : nullptr);
 	file_loaders_equal_insert_seq();
+	sizing_ctor_and_load_header();
 	parallel_filter_replay(argc > 2 ? argv[2] : nullptr);
 	if (g_fail) {
 		std::fprintf(stderr, "%d checks failed\n", g_fail);
