@@ -299,6 +299,30 @@ def test_bench_two_ranks_rehearsal(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_four_ranks_routed_windows_rehearsal(tmp_path):
+    """bench.py's N = 8 code path -- the routed exchange with position windows, as config 4 takes it -- rehearsed
+    with four ranks on the one GPU over gloo: 2^37 bits in windows of 2^36, every k-mer must come back a hit"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BTLBF_BENCH_REHEARSAL="1", PYTHONPATH=root, BTLBF_SHARD_MODE="routed",
+               BTLBF_ROUTE_WINDOW_BITS="36")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1",
+           "--warmup", "1", "--reads", "300000", "--log2-bits", "35", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["value"] > 0 and d["config"]["collective_world_size"] == 4
+    assert d["config"]["kmers_per_pass"] == 4 * 300000 * 120
+    assert "partitioned routing" in d["config"]["parallelism"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,world", [("exchange", 2), ("gather", 2), ("gather", 4)])
 def test_sharded_counting_filter_two_ranks_one_gpu(tmp_path, mode, world):
     """the counting filter shards like the bit filter -- incrementAll is shard-local at the
