@@ -148,14 +148,17 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	__syncthreads();
 	STAMP(4);
 	{
-		// bins are owned by lanes (P <= NT): wave v owns bins [64v, 64v+64) and flushes them itself,
-		// through its private slice of the flush list -- no workgroup barrier in between.  (Spreading 512
-		// bins over all 16 waves, 32 each, was measured: the same time and 5 % more instructions, because
-		// the waves without bins skip this block outright.)
-		const uint32_t b = tid, lane = tid & 63;
-		constexpr uint32_t bpw = 64;
+		// bins are owned by lanes (P <= NT): wave v owns bins [v*bpw, (v+1)*bpw) and flushes them itself,
+		// through its private slice of the flush list -- no workgroup barrier in between.  With at least half
+		// as many bins as threads a wave owns 64 (spreading 512 bins over all 16 waves was measured: the same
+		// time and 5 % more instructions, because the waves without bins skip this block outright); with FEW
+		// bins -- the 64-way split passes of a multi-GPU owner -- they are spread over all waves, or one wave
+		// would flush everything (owner side of the C4 geometry: 0.65 -> 0.49 s per pass)
+		const uint32_t lane = tid & 63;
+		const uint32_t bpw = P >= NT / 2 ? 64u : (P + NT / 64 - 1) / (NT / 64);
+		const uint32_t b = (tid >> 6) * bpw + lane;
 		uint32_t nfl = 0, rd0 = 0, w0 = 0;
-		if (b < P) {
+		if (lane < bpw && b < P) {
 			const uint32_t w = l.pt[b];
 			const uint32_t occ = w & 0xffffu;           // ring content + everything offered this round
 			const uint32_t avail = occ < SC ? occ : SC; // entries that really sit in the ring

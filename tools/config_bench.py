@@ -59,6 +59,7 @@ def main():
     km = n * (L - 25 + 1)
     t1, _ = timed(lambda: cb.insertSeqs(reads, read_len=L))
     t2, _ = timed(lambda: cb.insertSeqs(reads, read_len=L))
+    cb.containsSeqs(reads, read_len=L, want_valid=False, want_counts=True)  # first partitioned call: scratch allocation
     tq, (_, _, c) = timed(lambda: cb.containsSeqs(reads, read_len=L, want_valid=False, want_counts=True))
     out["C3"] = {"insert_Mkmers_s": 2 * km / (t1 + t2) / 1e6, "query_Mkmers_s": km / tq / 1e6, "hits": c.tolist(),
                  "kmers": km}
