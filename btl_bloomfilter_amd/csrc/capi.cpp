@@ -84,6 +84,10 @@ struct btlbf_filter {
 	unsigned bits_per_counter = 8;
 	unsigned shard_index = 0, shard_count = 1;
 	void* d_data = nullptr;
+	// btlbf_clear is LAZY: it only sets this.  The next partitioned insert builds every segment from zero in LDS
+	// and writes it (no memset of the array, no read sweep for that batch); any other entry point that touches
+	// the array zeroes it first (materialize_clear)
+	bool lazy_zero = false;
 	ModParams mod{};
 	HashParams hp{};
 	// spaced seeds
@@ -130,6 +134,21 @@ struct FilterLock {
 	FilterLock(const FilterLock&) = delete;
 	FilterLock& operator=(const FilterLock&) = delete;
 };
+
+// a pending btlbf_clear takes effect now, on the stream of the operation that needs the array
+hipError_t materialize_clear(btlbf_filter* f, hipStream_t s)
+{
+	if (!f || !f->lazy_zero)
+		return hipSuccess;
+	f->lazy_zero = false;
+	return hipMemsetAsync(f->d_data, 0, f->alloc_bytes, s);
+}
+#define MATERIALIZE(f, s)                                                                              \
+	do {                                                                                               \
+		hipError_t em__ = materialize_clear(const_cast<btlbf_filter*>(f), static_cast<hipStream_t>(s)); \
+		if (em__ != hipSuccess)                                                                        \
+			return fail(BTLBF_EHIP, "clearing the filter failed: %s", hipGetErrorString(em__));         \
+	} while (0)
 
 // times one kernel launch with a pair of events when profiling is on
 struct ProfSpan {
@@ -474,9 +493,8 @@ int make_filter(btlbf_filter** out, int kind, uint64_t size, uint64_t size_bytes
 		return fail(e == hipErrorOutOfMemory ? BTLBF_ENOMEM : BTLBF_EHIP, "hipMalloc(%llu bytes): %s",
 		            (unsigned long long)f->alloc_bytes, hipGetErrorString(e));
 	}
-	e = hipMemset(f->d_data, 0, f->alloc_bytes);
-	if (e == hipSuccess)
-		e = hipMalloc((void**)&f->d_scalar, 64);
+	f->lazy_zero = true; // a new filter is a cleared filter: zeroed by whoever touches the array first
+	e = hipMalloc((void**)&f->d_scalar, 64);
 	if (e == hipSuccess)
 		e = hipDeviceSynchronize();
 	if (e != hipSuccess) {
@@ -718,7 +736,16 @@ extern "C" uint64_t btlbf_get_n_entry(const btlbf_filter* f) { return f->n_entry
 extern "C" uint64_t btlbf_get_t_entry(const btlbf_filter* f) { return f->t_entry; }
 extern "C" void btlbf_set_n_entry(btlbf_filter* f, uint64_t v) { f->n_entry = v; }
 extern "C" void btlbf_set_t_entry(btlbf_filter* f, uint64_t v) { f->t_entry = v; }
-extern "C" void* btlbf_device_ptr(const btlbf_filter* f) { return f->d_data; }
+extern "C" void* btlbf_device_ptr(const btlbf_filter* f)
+{
+	if (f && f->lazy_zero) { // a caller that looks at the raw array must see a pending clear
+		FilterLock lk__(f);
+		DeviceGuard g(f->device);
+		(void)materialize_clear(const_cast<btlbf_filter*>(f), nullptr);
+		(void)hipDeviceSynchronize();
+	}
+	return f->d_data;
+}
 extern "C" int btlbf_device(const btlbf_filter* f) { return f->device; }
 
 extern "C" int btlbf_clear(btlbf_filter* f, void* stream)
@@ -726,8 +753,8 @@ extern "C" int btlbf_clear(btlbf_filter* f, void* stream)
 	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
-	DeviceGuard g(f->device);
-	HIP_TRY(hipMemsetAsync(f->d_data, 0, f->alloc_bytes, static_cast<hipStream_t>(stream)));
+	(void)stream;
+	f->lazy_zero = true; // zeroed by whoever touches the array next (see btlbf_filter::lazy_zero)
 	return BTLBF_OK;
 }
 
@@ -739,6 +766,7 @@ extern "C" int btlbf_upload(btlbf_filter* f, const void* src, uint64_t offset, u
 	if (offset + nbytes > f->local_bytes)
 		return fail(BTLBF_EINVAL, "upload range exceeds the filter");
 	DeviceGuard g(f->device);
+	MATERIALIZE(f, nullptr);
 	HIP_TRY(hipDeviceSynchronize());
 	HIP_TRY(hipMemcpy(static_cast<uint8_t*>(f->d_data) + offset, src, nbytes, hipMemcpyHostToDevice));
 	return BTLBF_OK;
@@ -752,6 +780,7 @@ extern "C" int btlbf_download(const btlbf_filter* f, void* dst, uint64_t offset,
 	if (offset + nbytes > f->local_bytes)
 		return fail(BTLBF_EINVAL, "download range exceeds the filter");
 	DeviceGuard g(f->device);
+	MATERIALIZE(f, nullptr);
 	HIP_TRY(hipDeviceSynchronize()); // DEVICE-mode calls may have run on non-blocking user streams
 	HIP_TRY(hipMemcpy(dst, static_cast<const uint8_t*>(f->d_data) + offset, nbytes, hipMemcpyDeviceToHost));
 	return BTLBF_OK;
@@ -813,6 +842,14 @@ extern "C" int btlbf_load(btlbf_filter** out, int kind, const char* path, unsign
 	f->dfpr = ph.dfpr;
 	f->n_entry = ph.n_entry;
 	f->t_entry = ph.t_entry;
+	{
+		DeviceGuard g0(device);
+		if (materialize_clear(f, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+			fclose(fp);
+			btlbf_destroy(f);
+			return fail(BTLBF_EHIP, "clearing the filter failed");
+		}
+	}
 	// body: stream through a pinned bounce buffer
 	const size_t chunk = 64u << 20;
 	void* bounce = nullptr;
@@ -924,6 +961,7 @@ extern "C" int btlbf_store_shard(btlbf_filter* f, const char* path)
 	if (!f || !path)
 		return fail(BTLBF_EINVAL, "null argument");
 	DeviceGuard g(f->device);
+	MATERIALIZE(f, nullptr);
 	HIP_TRY(hipDeviceSynchronize());
 	const std::string hdr = header_text(f);
 	const int flags = O_WRONLY | O_CREAT | (f->shard_count == 1 ? O_TRUNC : 0);
@@ -1020,6 +1058,7 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 	}
 	DeviceGuard g(f->device);
 	hipStream_t s = static_cast<hipStream_t>(stream);
+	MATERIALIZE(f, s);
 	SeqView v;
 	rc = make_view(v, seq, len, layout, mem, s);
 	if (rc)
@@ -1374,30 +1413,66 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, Par
 	return BTLBF_OK;
 }
 
+// entries a FRESH batch (below) may report as explicit positions instead of staging them
+static constexpr uint64_t kFreshSpillCap = 16ull << 20;
+// inserts (fresh or not) and queries reserve the same tail of the scratch, so that alternating between them
+// never changes the scratch size (a re-allocation of ~100 GB costs seconds)
+static constexpr uint64_t kPartExtraBytes = std::max<uint64_t>(kFailBytes, 256 + kFreshSpillCap * 8);
+
 int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* done)
 {
 	*done = false;
+	// A pending btlbf_clear is carried out by the first batch itself: pass C builds every segment from zero in
+	// LDS and writes it -- no memset of the array and no read sweep for that batch.  Pass C would also wipe what
+	// the overflow paths of passes A and B write straight into the array, so a fresh batch reports those entries
+	// as explicit positions instead (as the multi-GPU routing does) and they are applied after its last pass C;
+	// more of them than the list holds (heavily skewed input) and the batch is redone the ordinary way.
 	PartPlan pl;
 	PartTiling tiling;
 	uint8_t* extra = nullptr;
 	bool ok = false;
-	int rc = part_prepare(f, base, 0, pl, &tiling, &extra, &ok);
+	int rc = part_prepare(f, base, kPartExtraBytes, pl, &tiling, &extra, &ok);
 	if (rc || !ok)
 		return rc;
 	const uint64_t total_tiles = tiling.n_tiles;
-	PartSide sd;
-	memset(&sd, 0, sizeof sd);
-	sd.counting = f->kind == BTLBF_COUNTING8;
 	for (uint64_t t0 = 0; t0 < total_tiles; t0 += pl.tiles_per_batch) {
 		SeqArgs a = base;
 		a.first_tile = t0;
 		a.n_tiles = std::min<uint64_t>(pl.tiles_per_batch, total_tiles - t0);
-		{
-			ProfSpan ps(f, BTLBF_PROF_INSERT_HASH, s);
-			HIP_TRY(launch_part_hash(a, pl.lv[0].out(), pl.lv[0].shift, sd, 0, s));
+		for (int attempt = 0; attempt < 2; ++attempt) {
+			const bool fresh = f->lazy_zero;
+			PartSide sd;
+			memset(&sd, 0, sizeof sd);
+			sd.counting = f->kind == BTLBF_COUNTING8;
+			if (fresh) {
+				sd.fresh = 1;
+				sd.pos_base = f->mod.shard_lo;
+				sd.spill_count = reinterpret_cast<unsigned long long*>(extra);
+				sd.spill_list = reinterpret_cast<uint64_t*>(extra + 256);
+				sd.spill_cap = kFreshSpillCap;
+				HIP_TRY(hipMemsetAsync(sd.spill_count, 0, 8, s));
+			}
+			{
+				ProfSpan ps(f, BTLBF_PROF_INSERT_HASH, s);
+				HIP_TRY(launch_part_hash(a, pl.lv[0].out(), pl.lv[0].shift, sd, 0, s));
+			}
+			if ((rc = run_levels(f, pl, pl.lv[0].in(), sd, 0, s)))
+				return rc;
+			if (!fresh)
+				break;
+			f->lazy_zero = false; // every segment has been written
+			unsigned long long n_spill = 0;
+			HIP_TRY(hipMemcpyAsync(&n_spill, sd.spill_count, 8, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			if (n_spill <= kFreshSpillCap) {
+				PartSide plain;
+				memset(&plain, 0, sizeof plain);
+				plain.counting = sd.counting;
+				HIP_TRY(launch_spill(f->d_data, sd.spill_list, n_spill, f->mod.shard_lo, f->mod.shard_len, 0, plain, s));
+				break;
+			}
+			HIP_TRY(hipMemsetAsync(f->d_data, 0, f->alloc_bytes, s)); // start over, the ordinary way
 		}
-		if ((rc = run_levels(f, pl, pl.lv[0].in(), sd, 0, s)))
-			return rc;
 	}
 	*done = true;
 	return BTLBF_OK;
@@ -1441,7 +1516,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	PartTiling tiling;
 	uint8_t* extra = nullptr;
 	bool ok = false;
-	int rc = part_prepare(f, base, kFailBytes, pl, &tiling, &extra, &ok);
+	int rc = part_prepare(f, base, kPartExtraBytes, pl, &tiling, &extra, &ok);
 	if (rc || !ok)
 		return rc;
 	const uint64_t total_tiles = tiling.n_tiles;
@@ -1933,6 +2008,7 @@ extern "C" int btlbf_apply_routed_bins(btlbf_filter* f, const void* recv_ent, co
 		return fail(BTLBF_EINVAL, "query needs a fail list");
 	DeviceGuard g(f->device);
 	hipStream_t s = static_cast<hipStream_t>(stream);
+	MATERIALIZE(f, s);
 	const LayoutParams lay = layout_params(layout);
 	RoutePlan rp;
 	int rc = route_plan(f, plan_len, lay, n_shards, rp);
@@ -1987,6 +2063,7 @@ extern "C" int btlbf_apply_spill(btlbf_filter* f, const uint64_t* global_pos, ui
 	if (!f || (n && !global_pos))
 		return fail(BTLBF_EINVAL, "null argument");
 	DeviceGuard g(f->device);
+	MATERIALIZE(f, stream);
 	PartSide sd;
 	memset(&sd, 0, sizeof sd);
 	sd.fail_list = fail_list;
@@ -2059,6 +2136,7 @@ extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
 				return BTLBF_OK;
 			}
 		}
+		MATERIALIZE(f, s);
 	} else {
 		// a counting shard keeps the increments inside its window; the conservative update needs all h
 		// counters of a k-mer, which live on different shards
@@ -2079,6 +2157,7 @@ extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
 				return BTLBF_OK;
 			}
 		}
+		MATERIALIZE(f, s);
 		if (order == BTLBF_ORDER_SERIAL) {
 			// hash on all CUs, then apply the rows in buffer order on a single lane
 			DevBuf hashes, valid;
@@ -2154,6 +2233,7 @@ int run_hash_rows(btlbf_filter* f, int hop, const uint64_t* hashes, uint64_t n, 
 		return fail(BTLBF_EINVAL, "only insert is defined on a single shard");
 	DeviceGuard g(f->device);
 	hipStream_t s = static_cast<hipStream_t>(stream);
+	MATERIALIZE(f, s);
 	DevBuf hb;
 	const uint64_t* d_h = hashes;
 	if (mem == BTLBF_HOST) {
@@ -2292,6 +2372,7 @@ static int popcount_mode(btlbf_filter* f, int mode, uint64_t* out)
 	if (!f || !out)
 		return fail(BTLBF_EINVAL, "null argument");
 	DeviceGuard g(f->device);
+	MATERIALIZE(f, nullptr);
 	HIP_TRY(hipDeviceSynchronize()); // DEVICE-mode calls may have run on non-blocking user streams
 	HIP_TRY(hipMemset(f->d_scalar, 0, 8));
 	HIP_TRY(launch_popcount(f->d_data, f->alloc_bytes, mode, f->thr, f->d_scalar, nullptr));
@@ -2326,6 +2407,8 @@ extern "C" int btlbf_compare(btlbf_filter* a, btlbf_filter* b, uint64_t* out3)
 	    a->mod.shard_lo != b->mod.shard_lo || a->device != b->device)
 		return fail(BTLBF_EINVAL, "btlbf_compare: the two filters differ in kind, size, shard range or device");
 	DeviceGuard g(a->device);
+	MATERIALIZE(a, nullptr);
+	MATERIALIZE(b, nullptr);
 	HIP_TRY(hipDeviceSynchronize()); // whatever streams the two filters were last used on
 	DevBuf acc;
 	HIP_TRY(acc.alloc(24));
@@ -2359,6 +2442,7 @@ extern "C" int btlbf_rank_create(btlbf_rank** out, btlbf_filter* f)
 		return fail(BTLBF_EINVAL, "rank structure: needs a whole bit filter");
 	FilterLock lk__(f);
 	DeviceGuard g(f->device);
+	MATERIALIZE(f, nullptr);
 	HIP_TRY(hipDeviceSynchronize());
 	btlbf_rank* r = new btlbf_rank();
 	r->device = f->device;
@@ -2482,6 +2566,7 @@ extern "C" int btlbf_insert_positions(btlbf_filter* f, const uint64_t* local_pos
 	if (f->kind != BTLBF_BLOOM)
 		return fail(BTLBF_EINVAL, "position routing is defined for bit filters");
 	DeviceGuard g(f->device);
+	MATERIALIZE(f, stream);
 	HIP_TRY(launch_positions(0, f->d_data, f->mod, local_pos, n, nullptr, static_cast<hipStream_t>(stream)));
 	return BTLBF_OK;
 }
@@ -2495,6 +2580,7 @@ extern "C" int btlbf_test_positions(btlbf_filter* f, const uint64_t* local_pos, 
 	if (f->kind != BTLBF_BLOOM)
 		return fail(BTLBF_EINVAL, "position routing is defined for bit filters");
 	DeviceGuard g(f->device);
+	MATERIALIZE(f, stream);
 	HIP_TRY(launch_positions(1, f->d_data, f->mod, local_pos, n, out, static_cast<hipStream_t>(stream)));
 	return BTLBF_OK;
 }
@@ -2608,6 +2694,7 @@ extern "C" int btlbf_microbench(btlbf_filter* f, int kind, uint64_t n_access, ui
 		*n_done = (rounds ? rounds : 1) * per_round;
 	}
 	DeviceGuard g(f->device);
+	MATERIALIZE(f, nullptr);
 	hipEvent_t e0, e1;
 	HIP_TRY(hipEventCreate(&e0));
 	HIP_TRY(hipEventCreate(&e1));

@@ -168,6 +168,10 @@ struct PartSide {
 	uint64_t spill_cap;
 	uint32_t counting;              // the array holds uint8_t counters (incrementAll / min >= threshold), not bits
 	uint32_t threshold;             // counting query: a probe fails when its counter is below this
+	uint32_t fresh;                 // insert into an array known to be all zero (a pending btlbf_clear): pass C builds
+	                                // every segment from zero in LDS and writes it -- no read of the old contents,
+	                                // untouched segments are written as zeros
+	uint32_t pad_;
 };
 
 // launchers (defined in the .hip files)

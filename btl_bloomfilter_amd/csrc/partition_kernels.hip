@@ -188,8 +188,8 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 	if (mine)
 		any = 1;
 	__syncthreads();
-	if (!any)
-		return; // untouched segment: no traffic at all
+	if (!any && !(sd.fresh && !QUERY))
+		return; // untouched segment: no traffic at all (a fresh insert still has to write its zeros)
 	const uint64_t seg_bytes = 1ull << (seg_shift - kUnitShift);
 	const uint64_t byte0 = (uint64_t)seg * seg_bytes;
 	const uint64_t seg_base = (uint64_t)seg << seg_shift;
@@ -230,13 +230,14 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 			BTLBF_FETCH(q[u], left[u], u);
 		}
 	}
+	const bool fresh = sd.fresh && !QUERY; // the array is known to be zero: nothing to fetch
 	for (uint32_t base = 0; base < n_vec; base += NT * kSegU) {
 		uint4 v[kSegU];
 #pragma unroll
 		for (int u = 0; u < kSegU; ++u) {
 			const uint32_t i = base + (uint32_t)u * NT + tid;
 			v[u] = make_uint4(0, 0, 0, 0);
-			if (i < n_vec)
+			if (i < n_vec && !fresh)
 				v[u] = g4[i];
 		}
 #pragma unroll

@@ -132,7 +132,13 @@ void btlbf_set_dfpr(btlbf_filter* f, double v);
 void* btlbf_device_ptr(const btlbf_filter* f);       /* the HBM array */
 int btlbf_device(const btlbf_filter* f);
 
-/* raw array access; offset/nbytes in bytes of the local array */
+/* raw array access; offset/nbytes in bytes of the local array.
+   btlbf_clear is LAZY (and so is creation: a new filter is a cleared filter): it only marks the array as
+   "all zero".  If the next thing that happens is a partitioned btlbf_insert_seqs, its first batch builds
+   every segment from zero in LDS and writes it out -- no memset sweep, no read of the old array -- and
+   anything else that looks at the array (direct insert, queries, download, store, popcount, compare,
+   shard/rank/row entry points, btlbf_device_ptr) zeroes it first, on its own stream.  Callers cannot
+   observe the difference; a caller that writes through btlbf_device_ptr gets a zeroed array. */
 int btlbf_clear(btlbf_filter* f, void* stream);
 int btlbf_upload(btlbf_filter* f, const void* host_src, uint64_t offset, uint64_t nbytes);
 int btlbf_download(const btlbf_filter* f, void* host_dst, uint64_t offset, uint64_t nbytes);

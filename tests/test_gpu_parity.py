@@ -650,6 +650,72 @@ def test_partitioned_query_equals_direct(bf, bits, miss_reads):
 
 
 # ---------------------------------------------------------------------------------------------
+# btlbf_clear is lazy (and a new filter is a cleared filter): the first partitioned insert builds every
+# segment from zero in LDS; every other entry point must see the zeros
+# ---------------------------------------------------------------------------------------------
+def test_lazy_clear_is_invisible(bf, tmp_path):
+    import torch
+
+    bits, h, k, L = 1 << 30, 4, 31, 150
+    reads = bf.synth_reads_device(42, 0, 60000, L)
+    skew = reads[:L].repeat(4000)  # overflows its bins: travels through the fresh batch's spill list
+    buf = torch.cat([reads, skew, reads[: 1000 * L]])
+    ref = bf.BloomFilter(bits, h, k)
+    ref.setInsertMode("direct")
+    ref.insertSeqs(buf, read_len=L)
+    want = hashlib.sha256(ref.download()).hexdigest()
+    # 1. a NEW filter: its first partitioned insert is a fresh one (several batches: only the first is)
+    a = bf.BloomFilter(bits, h, k)
+    a.setInsertMode("partitioned", scratch_bytes=192 << 20)
+    a.setProfiling(True)
+    a.insertSeqs(buf, read_len=L)
+    assert a.getProfile()["insert_hash"][1] >= 2
+    assert hashlib.sha256(a.download()).hexdigest() == want
+    # 2. clear, then everything that looks at the array sees zeros
+    a.clear()
+    assert a.getPop() == 0
+    a.insertSeqs(reads[: 10 * L], read_len=L)  # small batch with AUTO off -> partitioned, fresh
+    p1 = a.getPop()
+    a.clear()
+    assert not a.download().any()
+    a.clear()
+    a.setInsertMode("direct")
+    a.insertSeqs(reads[: 10 * L], read_len=L)
+    assert a.getPop() == p1
+    a.clear()
+    _, _, cnt = a.containsSeqs(reads, read_len=L, want_valid=False, want_counts=True)
+    assert cnt.tolist() == [60000 * 120, 0]
+    a.clear()
+    a.storeFilter(tmp_path / "empty.bf")
+    raw = open(tmp_path / "empty.bf", "rb").read()
+    assert raw.endswith(b"\0" * (bits // 8)) and len(raw) > bits // 8
+    a.clear()
+    hv, valid = bf.hash_seqs(reads[:L], h, k, read_len=L)
+    rows = hv.cpu().numpy().view(np.uint64)[: L - k + 1]
+    assert not a.contains(rows).any()
+    a.insert(rows)
+    assert a.contains(rows).all() and a.compare(ref)[1] == 0  # nothing set that the full filter lacks
+    # 3. clear + partitioned again: the cleared state, not the old bits, is what the fresh batch starts from
+    a.clear()
+    a.setInsertMode("partitioned")
+    a.insertSeqs(buf, read_len=L)
+    assert hashlib.sha256(a.download()).hexdigest() == want
+    a.insertSeqs(buf, read_len=L)  # not fresh any more: ORs into what is there
+    assert hashlib.sha256(a.download()).hexdigest() == want
+    # 4. counting filter: incrementAll through a fresh batch, saturation included
+    c1, c2 = bf.CountingBloomFilter(1 << 27, 3, 25, 2), bf.CountingBloomFilter(1 << 27, 3, 25, 2)
+    sat = reads[: 3 * L].repeat(300)
+    cb = torch.cat([reads, sat])
+    c1.setInsertMode("direct")
+    c2.setInsertMode("partitioned")
+    for c in (c1, c2):
+        c.insertSeqs(cb, read_len=L, increment_all=True)
+        c.clear()
+        c.insertSeqs(cb, read_len=L, increment_all=True)
+    assert c2.compare(c1) == (0, 0, 0) and c1.download().max() == 255
+
+
+# ---------------------------------------------------------------------------------------------
 # the SWIG module's surface (swig/BloomFilter.i): KmerBloomFilter + insertSeq from Python
 # ---------------------------------------------------------------------------------------------
 def test_swig_surface_kmer_bloom_filter(bf, oracle, tmp_path):

@@ -64,6 +64,8 @@ def main():
     out["C3"] = {"insert_Mkmers_s": 2 * km / (t1 + t2) / 1e6, "query_Mkmers_s": km / tq / 1e6, "hits": c.tolist(),
                  "kmers": km}
     cb.clear()
+    cb.insertSeqs(reads, read_len=L, increment_all=True)  # warm-up: this path's own scratch size
+    cb.clear()
     ta, _ = timed(lambda: cb.insertSeqs(reads, read_len=L, increment_all=True))
     out["C3"]["increment_all_Mkmers_s"] = km / ta / 1e6
     print(json.dumps(out))
