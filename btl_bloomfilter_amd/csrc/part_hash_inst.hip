@@ -45,6 +45,9 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 
 	uint32_t* words = static_cast<uint32_t*>(a.filter);
 	const uint32_t ent_mask = bin_shift >= 32 ? 0xffffffffu : (1u << bin_shift) - 1;
+	// a power-of-two filter taken whole: bin and entry are bit fields of the hash itself (no 64-bit `& mask` first)
+	const uint32_t bin_mask = (uint32_t)(a.mod.mask >> bin_shift);
+	const uint32_t ent_mask_p2 = ent_mask & (uint32_t)a.mod.mask; // a filter smaller than one bin
 	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, ((uint64_t)b << bin_shift) | v); };
 	const uint64_t out_bytes = ((a.len + 63) / 64) * 8;
 	uint32_t my_valid = 0;
@@ -120,6 +123,12 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 #ifdef BTLBF_EXP_NOHASH
 				uint64_t p = (wh.bcan + (uint64_t)i * 0x9E3779B97F4A7C15ULL) & a.mod.mask;
 #else
+				if (POW2 && !WINDOW) {
+					const uint64_t hv = wh.at(i);
+					bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
+					val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
+					continue;
+				}
 				uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
 #endif
 				if (WINDOW) {

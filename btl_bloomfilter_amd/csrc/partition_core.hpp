@@ -23,8 +23,9 @@ struct PartLds {
 	uint32_t* pt;      // [P] low 16 bits: entries in the ring (+ offered this round); high 16: ring write position
 	uint32_t* fl;      // [P] entries flushed from the bin this round (multiple of 32)
 	uint32_t* written; // [P] chunks written to this workgroup's region of the bin
-	uint16_t* flist;   // [kFlushItems] flush items, a private slice per wave: bin | ring chunk << 10 ...
-	uint32_t* fwc;     // [kFlushItems] ... and the chunk's index inside the region (0xffffffff: over capacity)
+	uint16_t* flist;   // [kFlushItems] flush items, a private slice per wave: chunk index in `stage` ...
+	uint32_t* fwc;     // [kFlushItems] ... and the chunk's index in the output array (0xffffffff: over capacity)
+	uint32_t* dummy;   // [64] one word per lane: where an entry that found its ring full is "written" for now
 	uint32_t sc_shift; // log2(SC)
 };
 
@@ -38,7 +39,7 @@ __host__ __device__ inline uint32_t part_pow2ceil(uint32_t x)
 
 __host__ __device__ inline uint32_t part_lds_bytes(uint32_t P)
 {
-	return kStageEntries * 4 + 3 * P * 4 + kFlushItems * 6 + 16;
+	return kStageEntries * 4 + 3 * P * 4 + kFlushItems * 6 + 64 * 4 + 16;
 }
 
 __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
@@ -49,7 +50,8 @@ __device__ __forceinline__ PartLds part_carve(uint8_t* base, uint32_t P)
 	l.fl = l.pt + P;
 	l.written = l.fl + P;
 	l.fwc = l.written + P;
-	l.flist = reinterpret_cast<uint16_t*>(l.fwc + kFlushItems);
+	l.dummy = l.fwc + kFlushItems;
+	l.flist = reinterpret_cast<uint16_t*>(l.dummy + 64);
 	uint32_t pc = part_pow2ceil(P < 32 ? 32 : P), sh = 0;
 	while ((kStageEntries >> sh) > pc)
 		++sh; // kStageEntries / 2^sh == pc  ->  SC = 2^sh
@@ -112,7 +114,8 @@ static __device__ uint64_t g_stamp_out[16];
 //  3. late entries move into the ring space the flush freed, or overflow.
 // No barrier is needed after phase 3: the next round's phase 1 only touches pt (final since phase 2)
 // and ring slots behind the late ones; its phase 2 comes after its own barrier.
-template <int NT, int E, int G, class OVF>
+// ALL: every entry of every lane exists (no `live` tests at all: the full rounds of pass B).
+template <int NT, int E, int G, bool ALL = false, class OVF>
 __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
                                            const uint32_t (&bin)[E], const uint32_t (&val)[E], const uint32_t live,
                                            OVF&& ovf STAMP_ARGS)
@@ -121,27 +124,36 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	const uint32_t P = o.P;
 	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
 	uint32_t old[E];
-	uint32_t late = 0; // bit e: entry e found no room before this round's flush
 	static_assert(E <= 32 && E % G == 0, "one flag bit per entry; whole groups");
 	// bit g of `live`: the G entries of group g exist (pass A: the H probes of one clean window).
 	// All atomics of the lane are issued back to back (independent), then consumed.
 #pragma unroll
 	for (int g = 0; g < E / G; ++g) {
-		if ((live >> g) & 1) {
+		if (ALL || ((live >> g) & 1)) {
 #pragma unroll
 			for (int e = g * G; e < (g + 1) * G; ++e)
 				old[e] = atomicAdd(&l.pt[bin[e]], 0x10001u);
+		} else {
+#pragma unroll
+			for (int e = g * G; e < (g + 1) * G; ++e)
+				old[e] = 0;
 		}
 	}
+	// An entry that finds room is written into its ring; one that does not is written to the lane's dummy word
+	// (no branch, no exec juggling per entry) and remembered as one bit per LANE: phase 3 looks at old[] again.
+	bool any_late = false;
+	uint32_t* const dummy = &l.dummy[tid & 63];
+	const uint32_t stage_shift = l.sc_shift + 2;
 #pragma unroll
 	for (int g = 0; g < E / G; ++g) {
-		if ((live >> g) & 1) {
+		if (ALL || ((live >> g) & 1)) {
 #pragma unroll
 			for (int e = g * G; e < (g + 1) * G; ++e) {
-				if ((old[e] & 0xffffu) < SC)
-					l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 16) & ring)] = val[e];
-				else
-					late |= 1u << e;
+				const bool fits = (old[e] & 0xffffu) < SC;
+				const uint32_t slot = __builtin_amdgcn_ubfe(old[e], 16, l.sc_shift);
+				uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l.stage) + (bin[e] << stage_shift) + slot * 4);
+				*(fits ? dst : dummy) = val[e];
+				any_late |= !fits;
 			}
 		}
 	}
@@ -180,10 +192,14 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 		const uint32_t incl = wave_scan_incl(nfl);
 		const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
 		const uint32_t slice = (tid >> 6) * ((bpw << l.sc_shift) >> kChunkShift);
+		// a flush item is (chunk of the staging area, chunk of the output array): both are worked out here, once
+		// per chunk, and the part that depends on the bin alone is the same in every round (hoisted)
+		const uint32_t cshift = l.sc_shift - kChunkShift; // log2(chunks per ring)
+		const uint32_t cbase = ((bin0 + b) * o.regions + region) * o.cap;
 		for (uint32_t c = 0; c < nfl; ++c) {
 			const uint32_t j = slice + incl - nfl + c;
-			l.flist[j] = (uint16_t)(b | ((((rd0 >> kChunkShift) + c) & (ring >> kChunkShift)) << 10));
-			l.fwc[j] = w0 + c < o.cap ? w0 + c : 0xffffffffu;
+			l.flist[j] = (uint16_t)((b << cshift) + (((rd0 >> kChunkShift) + c) & (ring >> kChunkShift)));
+			l.fwc[j] = w0 + c < o.cap ? cbase + w0 + c : 0xffffffffu;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
@@ -193,12 +209,11 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 		const uint32_t l4 = lane & (kLanesPerChunk - 1);
 		for (uint32_t j = lane / kLanesPerChunk; j < total; j += 64 / kLanesPerChunk) {
 			const uint32_t it = l.flist[slice + j], wc = l.fwc[slice + j];
-			const uint32_t fb = it & 1023, rc = it >> 10;
-			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[(fb << l.sc_shift) + (rc << kChunkShift) + l4 * 4]);
+			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[it * kChunk + l4 * 4]);
 			if (wc != 0xffffffffu) {
-				const uint64_t dst = ((uint64_t)((bin0 + fb) * o.regions + region) * o.cap + wc) * kChunk + l4 * 4;
-				*reinterpret_cast<uint4*>(&o.ent[dst]) = v;
+				*reinterpret_cast<uint4*>(&o.ent[(uint64_t)wc * kChunk + l4 * 4]) = v;
 			} else {
+				const uint32_t fb = it >> cshift;
 				ovf(fb, v.x);
 				ovf(fb, v.y);
 				ovf(fb, v.z);
@@ -209,11 +224,14 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	__syncthreads();
 	STAMP(6);
 	// entries that did not fit before the flush: into the freed ring space, else overflow
-	if (late) {
+	if (any_late) {
 #pragma unroll
 		for (int e = 0; e < E; ++e) {
-			if ((late >> e) & 1) {
-				if ((old[e] & 0xffffu) - l.fl[bin[e]] < SC)
+			const uint32_t occ = old[e] & 0xffffu; // 0 for an entry that does not exist
+			if (occ >= SC) {
+				// a ring of ONE chunk always flushed that chunk when an entry found it full
+				const uint32_t f = l.sc_shift == kChunkShift ? SC : l.fl[bin[e]];
+				if (occ - f < SC)
 					l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 16) & ring)] = val[e];
 				else
 					ovf(bin[e], val[e]);

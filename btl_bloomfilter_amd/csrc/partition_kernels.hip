@@ -73,35 +73,62 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 			n = in.cap * kChunk;
 		const uint4* src = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg * in.cap * kChunk);
 		const uint32_t n_vec = (n + 3) / 4;
-		// software pipeline: the next round's loads are in flight while this round is partitioned
-		uint4 nxt[kVec];
-#pragma unroll
-		for (int v = 0; v < kVec; ++v) {
-			const uint32_t i = (uint32_t)v * kPartThreads + tid;
-			nxt[v] = i < n_vec ? src[i] : make_uint4(0, 0, 0, 0);
-		}
-		for (uint32_t base = 0; base < n_vec; base += kPartThreads * kVec) {
-			uint32_t bin[kVec * 4], val[kVec * 4];
-			uint32_t live = 0;
+		if (n_vec == 0)
+			continue;
+		// software pipeline: the next round's loads are in flight while this round is partitioned.  A vector
+		// slot beyond the region re-reads the region's last vector (a plain clamped load: no branch, no
+		// zero-fill); only the region's last round can have such slots, and it masks them with `live`.
+		const uint32_t last_vec = n_vec - 1;
+		auto fetch = [&](uint4 (&dst)[kVec], uint32_t base) {
 #pragma unroll
 			for (int v = 0; v < kVec; ++v) {
-				const uint32_t e4[4] = {nxt[v].x, nxt[v].y, nxt[v].z, nxt[v].w};
-				// whole vectors: a region's tail is padded with copies of its last entry (part_finish),
-				// which is harmless for OR / test; counting takes exactly n entries
-				const uint32_t vi = base + (uint32_t)v * kPartThreads + tid;
-				if (!EXACT)
-					live |= (uint32_t)(vi < n_vec) << v;
+				const uint32_t i = base + (uint32_t)v * kPartThreads + tid;
+				dst[v] = src[i < last_vec ? i : last_vec];
+			}
+		};
+		auto round = [&](const uint4 (&cur)[kVec], uint32_t base) {
+			uint32_t bin[kVec * 4], val[kVec * 4];
+#pragma unroll
+			for (int v = 0; v < kVec; ++v) {
+				const uint32_t e4[4] = {cur[v].x, cur[v].y, cur[v].z, cur[v].w};
 #pragma unroll
 				for (int c = 0; c < 4; ++c) {
 					bin[v * 4 + c] = e4[c] >> sub_shift;
 					val[v * 4 + c] = e4[c] & sub_mask;
-					if (EXACT)
-						live |= (uint32_t)(vi * 4 + c < n) << (v * 4 + c);
 				}
-				const uint32_t i = base + kPartThreads * kVec + (uint32_t)v * kPartThreads + tid;
-				nxt[v] = i < n_vec ? src[i] : make_uint4(0, 0, 0, 0);
 			}
-			part_round<kPartThreads, kVec * 4, EXACT ? 1 : 4>(pl, out, bin0, g, bin, val, live, ovf STAMP_PASS);
+			// EXACT: every entry counts, so the padded tail of the last vector is not taken whole
+			const bool full = EXACT ? (uint64_t)(base + kPartThreads * kVec) * 4 <= n : base + kPartThreads * kVec <= n_vec;
+			if (full) {
+				part_round<kPartThreads, kVec * 4, EXACT ? 1 : 4, true>(pl, out, bin0, g, bin, val, 0, ovf STAMP_PASS);
+			} else {
+				uint32_t live = 0;
+#pragma unroll
+				for (int v = 0; v < kVec; ++v) {
+					const uint32_t vi = base + (uint32_t)v * kPartThreads + tid;
+					if (!EXACT)
+						live |= (uint32_t)(vi < n_vec) << v;
+#pragma unroll
+					for (int c = 0; c < 4; ++c)
+						if (EXACT)
+							live |= (uint32_t)(vi * 4 + c < n) << (v * 4 + c);
+				}
+				part_round<kPartThreads, kVec * 4, EXACT ? 1 : 4, false>(pl, out, bin0, g, bin, val, live, ovf STAMP_PASS);
+			}
+		};
+		// two register sets take turns (no copies between rounds)
+		uint4 va[kVec], vb[kVec];
+		fetch(va, 0);
+		for (uint32_t base = 0; base < n_vec; base += 2 * kPartThreads * kVec) {
+			const uint32_t base1 = base + kPartThreads * kVec;
+			if (base1 < n_vec)
+				fetch(vb, base1);
+			round(va, base);
+			if (base1 >= n_vec)
+				break;
+			if (base1 + kPartThreads * kVec < n_vec)
+				fetch(va, base1 + kPartThreads * kVec);
+			round(vb, base1);
 		}
 	}
 	part_finish<kPartThreads>(pl, out, bin0, g, ovf);
