@@ -22,8 +22,9 @@ __device__ __forceinline__ uint64_t sror1(uint64_t x)
 {
 	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
 	const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, 1); // lo>>1 | hi<<31
-	const uint32_t t = ((hi >> 1) & ~1u) | (lo & 1u);          // v_bfi
-	const uint32_t nhi = (t & 0x7fffffffu) | ((hi << 30) & 0x80000000u);
+	const uint32_t r = __builtin_amdgcn_alignbit(hi, hi, 1);   // hi rotated right: r[30:1] = hi[31:2], r[0] = hi[1]
+	const uint32_t ends = (r << 31) | (lo & 1u);               // v_and + v_lshl_or
+	const uint32_t nhi = (r & 0x7ffffffeu) | (ends & ~0x7ffffffeu); // v_bfi
 	return ((uint64_t)nhi << 32) | nlo;
 }
 
