@@ -24,11 +24,14 @@ f = m.BloomFilter(1 << 39, 4, 31)
 f.setInsertMode("partitioned")
 f.setProfiling(True)
 reads = m.synth_reads_device(42, 0, n, L)
+f.setQueryMode("partitioned")
 for rep in range(3):
     f.insertSeqs(reads, read_len=L)
+    f.containsSeqs(reads, read_len=L, want_valid=False)
     torch.cuda.synchronize()
     prof = f.getProfile()
 ms, calls = prof["insert_hash"]
+print("   per launch ms: " + "  ".join("%s %.3f" % (k, v[0] / v[1]) for k, v in prof.items() if v[1]))
 print("%-40s geom=%-6s pass A %.2f ms per launch (%d launches, %.2f ms per 1e9 k-mers)" % (
     os.path.basename(path or "libbtlbf.so"), os.environ.get("BTLBF_PART_GEOM", "auto"), ms / calls, calls,
     ms / (n * (L - 30) / 1e9)))
