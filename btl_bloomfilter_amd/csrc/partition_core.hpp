@@ -102,8 +102,9 @@ static __device__ uint64_t g_stamp_out[16];
 // (32-bit chunk indices: a pass's output holds fewer than 2^32 chunks).
 // `ovf(bin, val)` takes the entries that cannot be staged.
 //
-// pt[b] packs (ring write position << 16 | entries in the ring).  Three phases, two barriers:
-//  1. ONE returning LDS atomic per entry adds 0x10001: the old value is the entry's ring slot (high
+// pt[b] packs (4 * ring write position << 16 | entries in the ring); the position is kept in BYTES of the ring
+// (mod 2^16: rings hold at most 2^10 entries), so an entry's slot offset is one masked half-word.  Three phases, two barriers:
+//  1. ONE returning LDS atomic per entry adds 0x40001: the old value is the entry's ring slot (high
 //     half) and how many entries are ahead of it (low half; fewer than SC means it fits and is written
 //     now; otherwise it is "late").
 //  2. the lane that owns bin b (b = lane index) sees how much arrived, copies the bin's full 32-entry
@@ -132,7 +133,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 		if (ALL || ((live >> g) & 1)) {
 #pragma unroll
 			for (int e = g * G; e < (g + 1) * G; ++e)
-				old[e] = atomicAdd(&l.pt[bin[e]], 0x10001u);
+				old[e] = atomicAdd(&l.pt[bin[e]], 0x40001u);
 		} else {
 #pragma unroll
 			for (int e = g * G; e < (g + 1) * G; ++e)
@@ -143,15 +144,15 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 	// (no branch, no exec juggling per entry) and remembered as one bit per LANE: phase 3 looks at old[] again.
 	bool any_late = false;
 	uint32_t* const dummy = &l.dummy[tid & 63];
-	const uint32_t stage_shift = l.sc_shift + 2;
+	const uint32_t stage_shift = l.sc_shift + 2, ring4 = ring << 2;
 #pragma unroll
 	for (int g = 0; g < E / G; ++g) {
 		if (ALL || ((live >> g) & 1)) {
 #pragma unroll
 			for (int e = g * G; e < (g + 1) * G; ++e) {
 				const bool fits = (old[e] & 0xffffu) < SC;
-				const uint32_t slot = __builtin_amdgcn_ubfe(old[e], 16, l.sc_shift);
-				uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l.stage) + (bin[e] << stage_shift) + slot * 4);
+				const uint32_t slot4 = (old[e] >> 16) & ring4; // byte offset inside the ring
+				uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l.stage) + ((bin[e] << stage_shift) + slot4));
 				*(fits ? dst : dummy) = val[e];
 				any_late |= !fits;
 			}
@@ -179,12 +180,12 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 			// state for the next round (see above)
 			const uint32_t tot = occ - f;
 			const uint32_t nocc = tot < SC ? tot : SC;
-			l.pt[b] = (((w >> 16) - (tot - nocc)) << 16) | nocc;
+			l.pt[b] = (((w >> 16) - 4 * (tot - nocc)) << 16) | nocc;
 			l.fl[b] = f;
 			if (nfl) {
 				w0 = l.written[b];
 				l.written[b] = w0 + nfl;
-				rd0 = ((w >> 16) - occ) & ring; // read position of the ring: both halves of pt grew alike
+				rd0 = ((w >> 18) - occ) & ring; // read position of the ring: both halves of pt grew alike
 			}
 		}
 		// inclusive prefix sum of nfl over the wave (DPP row shifts + row broadcasts, no LDS) -> slots
@@ -232,7 +233,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 				// a ring of ONE chunk always flushed that chunk when an entry found it full
 				const uint32_t f = l.sc_shift == kChunkShift ? SC : l.fl[bin[e]];
 				if (occ - f < SC)
-					l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 16) & ring)] = val[e];
+					l.stage[(bin[e] << l.sc_shift) + ((old[e] >> 18) & ring)] = val[e];
 				else
 					ovf(bin[e], val[e]);
 			}
@@ -251,7 +252,7 @@ __device__ __forceinline__ void part_finish(const PartLds& l, const PartOut& o, 
 	const uint32_t tid = threadIdx.x, ln = tid & (kChunk - 1);
 	const uint32_t ring = (1u << l.sc_shift) - 1;
 	for (uint32_t b = tid / kChunk; b < o.P; b += NT / kChunk) {
-		const uint32_t w = l.pt[b], n = w & 0xffffu, hd = ((w >> 16) - n) & ring;
+		const uint32_t w = l.pt[b], n = w & 0xffffu, hd = ((w >> 18) - n) & ring;
 		const uint32_t w0 = l.written[b];
 		const uint32_t full = w0 < o.cap ? w0 : o.cap; // chunks of this region that really hold data
 		const uint64_t o0 = (uint64_t)((bin0 + b) * o.regions + region) * o.cap;
