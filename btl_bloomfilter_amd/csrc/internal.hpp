@@ -125,10 +125,23 @@ struct SeqArgs {
 	uint64_t first_tile;
 	uint64_t n_tiles;
 	uint64_t tiles_per_block;
+	// pass A's read grid (part_read_grid; rg_reads == 0: plain tiles of NT*8 window starts)
+	uint32_t rg_reads; // reads per tile
+	uint32_t rg_gpr;   // groups of 8 window starts per read
+	uint32_t rg_lpad;  // bytes a read occupies in the LDS tile (read_len rounded up to 8)
+	uint32_t rg_cap;   // bytes of dynamic LDS the tile image takes (reads + guard + two window bitmaps)
 };
 
 // How pass A cuts a buffer into tiles (partition_kernels.hip: part_tiling).  All host-side planning is in
 // these tiles.
+// Read grid of pass A (uniform layout): a tile is a whole number of reads, every read sits at an 8-byte aligned
+// offset of the LDS image, and a lane takes 8 consecutive window starts of ONE read -- no lane spends its
+// time on the k-1 window starts at a read's end that hold no k-mer (20 % of them for 150-base reads, k = 31).
+struct PartGrid {
+	uint32_t reads = 0, gpr = 0, lpad = 0, cap = 0;
+};
+bool part_read_grid(const HashParams& hp, uint32_t p0, const LayoutParams& lay, PartGrid* g);
+
 struct PartTiling {
 	uint32_t tile_bytes;      // window starts per tile = bytes from one tile's start to the next
 	uint64_t n_tiles;         // tiles covering the buffer

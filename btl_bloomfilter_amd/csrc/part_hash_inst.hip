@@ -28,7 +28,10 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 	__shared__ SeqShared sh;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t k = a.hp.k;
-	const uint32_t tile_cap = seq_tile_cap(kTile, k);
+	// read grid (internal.hpp PartGrid; never with the small geometry): tiles of rg_reads whole reads
+	const bool grid = !SMALL && a.rg_reads != 0;
+	const uint32_t tile_cap = grid ? a.rg_cap : seq_tile_cap(kTile, k);
+	const uint32_t tile_bytes = grid ? a.rg_reads * a.layout.read_len : (uint32_t)kTile; // window starts per tile
 	uint8_t* tile = dyn;
 	uint8_t* spaced_lds = dyn + tile_cap;
 	uint8_t* part_base = dyn + tile_cap + seq_spaced_bytes(a.hp);
@@ -58,15 +61,32 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 		t_end = a.first_tile + a.n_tiles;
 	const uint32_t L = a.layout.starts ? 0 : a.layout.read_len;
 	uint32_t tile_off = 0;
-	if (L && t_begin < t_end)
+	if (L && t_begin < t_end && !grid)
 		tile_off = (uint32_t)((t_begin * (uint64_t)kTile) % L);
-	const uint32_t tile_step = L ? (uint32_t)(kTile % L) : 0;
+	const uint32_t tile_step = L && !grid ? (uint32_t)(kTile % L) : 0;
+	// grid: the lane's 8 window starts are starts 8m .. 8m+7 of read rd of the tile (the same in every tile);
+	// lanes beyond the grid look at the zeroed guard behind the last read and find no k-mer there
+	uint32_t grid_li0 = 0, grid_bit = 0;
+	uint32_t* grid_bm = nullptr; // two bitmaps of the tile's window starts, used by turns
+	uint32_t grid_bm_words = 0;
+	const bool want_bits = a.valid_bits || a.hit_bits;
+	if (grid) {
+		const uint32_t rd = tid / a.rg_gpr, m = tid - rd * a.rg_gpr;
+		const bool in_grid = rd < a.rg_reads;
+		grid_li0 = in_grid ? rd * a.rg_lpad + 8 * m : a.rg_reads * a.rg_lpad;
+		grid_bit = in_grid ? rd * L + 8 * m : 0xffffffffu;
+		grid_bm_words = ((tile_bytes / 8 + 15) / 16) * 4;
+		grid_bm = reinterpret_cast<uint32_t*>(tile + tile_cap) - 2 * grid_bm_words;
+		for (uint32_t i = tid; i < tile_cap / 4; i += NT) // pads, guard and bitmaps start as zeros
+			reinterpret_cast<uint32_t*>(tile)[i] = 0;
+	}
+	const uint32_t span = grid ? tile_bytes : 0; // bytes seq_stage_load requests (0: kTile + k - 1)
 
 	__syncthreads(); // tables and partition state ready
 	STAMP_DECL;
 	StageRaw<kPartW> raw;
 	if (t_begin < t_end)
-		seq_stage_load<NT, kPartW>(raw, a.seq, a.len, k, t_begin * (uint64_t)kTile);
+		seq_stage_load<NT, kPartW>(raw, a.seq, a.len, k, t_begin * (uint64_t)tile_bytes, span);
 	if (SMALL) {
 		// the first tile's words land here; every later tile's land inside the partition rounds (below), so
 		// the top of the loop never waits on vector memory -- a wait there would sit behind the flush stores
@@ -75,7 +95,7 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 			asm volatile("" : "+v"(raw.w[q]));
 	}
 	for (uint64_t t = t_begin; t < t_end; ++t) {
-		const uint64_t g0 = t * (uint64_t)kTile;
+		const uint64_t g0 = t * (uint64_t)tile_bytes;
 		STAMP(0);
 		// this tile's words were requested a whole tile ago; the next tile's are requested now and stay
 		// in flight while this one is hashed and partitioned
@@ -85,10 +105,16 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 		__syncthreads();
 		STAMP(3); // waiting for the other waves
 #else
-		const uint32_t mis = seq_stage_convert<NT, kPartW, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+		uint32_t mis = 0;
+		if (grid) {
+			seq_stage_convert_grid<NT, kPartW>(raw, tile, sh, a.seq, a.len, L, a.rg_lpad, tile_bytes, g0);
+			__syncthreads();
+		} else {
+			mis = seq_stage_convert<NT, kPartW, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+		}
 #endif
 		if (t + 1 < t_end)
-			seq_stage_load<NT, kPartW>(raw, a.seq, a.len, k, g0 + kTile);
+			seq_stage_load<NT, kPartW>(raw, a.seq, a.len, k, g0 + tile_bytes, span);
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
 
 		// the lane hashes its 8 consecutive windows with ONE start-up; after every 4 windows the
@@ -110,9 +136,18 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 		};
 		fake_windows([&](int w, bool ok, const WinHash<SPACED>& wh) {
 #else
-		seq_lane_windows<SPACED, kPartW, H>(tile, sh, a.hp, spaced_lds, tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
+		seq_lane_windows<SPACED, kPartW, H>(tile, sh, a.hp, spaced_lds, grid ? grid_li0 : tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
 #endif
 			vmask |= (uint32_t)ok << w;
+			if (w == kPartW - 1 && grid && want_bits && grid_bit != 0xffffffffu) {
+				// the lane's byte of the window bitmap sits at bit 8m of its read: collected in LDS (this
+				// tile's bitmap; the partition round below has the barriers) and written out whole afterwards
+				uint32_t* bm = grid_bm + ((t - t_begin) & 1) * grid_bm_words;
+				const uint32_t sh5 = grid_bit & 31;
+				atomicOr(&bm[grid_bit >> 5], vmask << sh5);
+				if (sh5 > 24)
+					atomicOr(&bm[(grid_bit >> 5) + 1], vmask >> (32 - sh5));
+			}
 			const int w4 = w % kPartHalf;
 			if (w4 == 0)
 				live = 0;
@@ -165,7 +200,26 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 					part_round<kPartThreads, kPartHalf * H, WINDOW ? 1 : H>(pl, out, 0, blockIdx.x, bin, val, live, ovf STAMP_PASS);
 			}
 		});
-		if (a.valid_bits || a.hit_bits) {
+		if (want_bits && grid) {
+			// this tile's bitmap is complete (two barriers since the last OR); the other one -- written out a
+			// tile ago -- is cleared for the next tile
+			uint32_t* bm = grid_bm + ((t - t_begin) & 1) * grid_bm_words;
+			uint32_t* other = grid_bm + (((t - t_begin) & 1) ^ 1) * grid_bm_words;
+			const uint8_t* bm8 = reinterpret_cast<const uint8_t*>(bm);
+			const uint64_t ob0 = g0 >> 3; // tiles are whole bytes of the bitmaps
+			// the buffer's last tile also writes the (zero) bytes up to the end of the bitmaps' last 64-bit word
+			const uint64_t left = out_bytes > ob0 ? out_bytes - ob0 : 0;
+			const uint32_t n_out = g0 + tile_bytes >= a.len || left < tile_bytes / 8 ? (uint32_t)left : tile_bytes / 8;
+			for (uint32_t i = tid; i < n_out; i += NT) {
+				const uint8_t v = i < tile_bytes / 8 ? bm8[i] : (uint8_t)0;
+				if (a.valid_bits)
+					a.valid_bits[ob0 + i] = v;
+				if (a.hit_bits)
+					a.hit_bits[ob0 + i] = v; // a query starts from "every clean window hits"
+			}
+			for (uint32_t i = tid; i < grid_bm_words; i += NT)
+				other[i] = 0;
+		} else if (want_bits) {
 			// one byte of the per-window bitmaps per lane
 			static_assert(kPartW == 8, "one bitmap byte per lane");
 			const uint64_t ob = (g0 >> 3) + tid;

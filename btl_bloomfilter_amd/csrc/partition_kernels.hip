@@ -24,6 +24,7 @@
 // one flush hold inside one round) take the overflow path: applied to the filter directly (single
 // GPU) or appended to a spill list of global positions (multi-GPU routing) -- never dropped.
 #include "partition_core.hpp"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -348,7 +349,7 @@ static bool part_want_small(uint32_t p0)
 }
 
 // with the positional seed table if it fits, else without (Horner start-up; spaced seeds cannot do without it)
-static bool part_front(const HashParams& hp_in, uint32_t p0, PartFront& fr)
+static bool part_front(const HashParams& hp_in, uint32_t p0, PartFront& fr, uint32_t tile_lds = 0)
 {
 	for (int geom = part_want_small(p0) ? 1 : 0; geom >= 0; --geom) {
 		fr.small = geom == 1;
@@ -362,7 +363,7 @@ static bool part_front(const HashParams& hp_in, uint32_t p0, PartFront& fr)
 					break;
 				hp.use_pos_tab = 0;
 			}
-			const uint32_t dyn = seq_tile_cap(fr.nt * kPartW, hp.k) + seq_spaced_bytes(hp) + rings;
+			const uint32_t dyn = (tile_lds && !fr.small ? tile_lds : seq_tile_cap(fr.nt * kPartW, hp.k)) + seq_spaced_bytes(hp) + rings;
 			if (dyn <= budget) {
 				fr.use_pos_tab = hp.use_pos_tab;
 				fr.dyn = dyn;
@@ -387,6 +388,49 @@ uint32_t part_hash_regions(const HashParams& hp, uint32_t p0, uint32_t cus)
 	return part_front(hp, p0, fr) && fr.small ? 2 * cus : cus;
 }
 
+// The read grid for (hash configuration, level-0 bins, layout), if it pays: uniform reads, the 1024-thread
+// geometry, the tile image fits the LDS next to the rings, and the lanes it keeps busy beat plain tiles by 5 %.
+// BTLBF_READ_GRID=0 turns it off (measurements).
+bool part_read_grid(const HashParams& hp, uint32_t p0, const LayoutParams& lay, PartGrid* g)
+{
+	*g = PartGrid();
+	const uint32_t L = lay.starts ? 0 : lay.read_len, k = hp.k;
+	if (L < 16 || L < k || L > 4096 || part_want_small(p0))
+		return false;
+	if (const char* e = getenv("BTLBF_READ_GRID"))
+		if (!strcmp(e, "0"))
+			return false;
+	const uint32_t wins = L - k + 1, gpr = (wins + 7) / 8;
+	uint32_t step = 8; // reads per tile: a multiple of `step` keeps a tile's window bitmap in whole bytes
+	while (step > 1 && ((uint64_t)(step / 2) * L) % 8 == 0)
+		step /= 2;
+	// every thread stages kPartW/4+1 words of a tile
+	const uint32_t max_bytes = (kPartW / 4 + 1) * kPartThreads * 4 - 16;
+	uint32_t reads = std::min<uint32_t>(kPartThreads / gpr, max_bytes / L);
+	if (const char* e = getenv("BTLBF_GRID_READS")) { // measurements: fewer reads per tile than fit
+		const uint32_t v = (uint32_t)atoi(e);
+		if (v >= 1 && v < reads)
+			reads = v;
+	}
+	reads -= reads % step;
+	if (reads == 0)
+		return false;
+	const double eff_grid = (double)reads * wins / (kPartThreads * kPartW), eff_plain = (double)wins / L;
+	if (eff_grid < 1.05 * eff_plain)
+		return false;
+	const uint32_t lpad = (L + 7) / 8 * 8;
+	const uint32_t bitmap = ((reads * L / 8 + 15) / 16) * 16; // one bit per window start of the tile
+	const uint32_t cap = ((reads * lpad + k + 8 + 15) / 16) * 16 + 2 * bitmap;
+	PartFront fr, plain;
+	if (!part_front(hp, p0, fr, cap) || fr.small || !part_front(hp, p0, plain) || fr.use_pos_tab != plain.use_pos_tab)
+		return false; // (not at the price of the positional seed table)
+	g->reads = reads;
+	g->gpr = gpr;
+	g->lpad = lpad;
+	g->cap = cap;
+	return true;
+}
+
 // how pass A cuts a buffer into tiles; all host-side planning is in these units
 PartTiling part_tiling(const HashParams& hp, uint32_t p0, const LayoutParams& lay, uint64_t len)
 {
@@ -395,6 +439,13 @@ PartTiling part_tiling(const HashParams& hp, uint32_t p0, const LayoutParams& la
 		fr = PartFront();
 	PartTiling t;
 	const uint32_t L = lay.starts ? 0 : lay.read_len;
+	PartGrid g;
+	if (part_read_grid(hp, p0, lay, &g)) {
+		t.tile_bytes = g.reads * L;
+		t.n_tiles = (len + t.tile_bytes - 1) / t.tile_bytes;
+		t.windows_per_tile = (double)g.reads * (L - hp.k + 1);
+		return t;
+	}
 	t.tile_bytes = fr.nt * kPartW;
 	t.n_tiles = (len + t.tile_bytes - 1) / t.tile_bytes;
 	t.windows_per_tile = (double)t.tile_bytes * (L ? (L >= hp.k ? (double)(L - hp.k + 1) / L : 0.0) : 1.0);
@@ -428,8 +479,14 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bi
 	if (a.n_tiles == 0)
 		return hipSuccess;
 	PartFront fr;
-	if (!part_front(a.hp, out.P, fr))
+	PartGrid g;
+	const bool grid = part_read_grid(a.hp, out.P, a.layout, &g);
+	if (!part_front(a.hp, out.P, fr, grid ? g.cap : 0))
 		return hipErrorInvalidValue;
+	a.rg_reads = g.reads;
+	a.rg_gpr = g.gpr;
+	a.rg_lpad = g.lpad;
+	a.rg_cap = g.cap;
 	a.hp.use_pos_tab = fr.use_pos_tab;
 	a.tiles_per_block = (a.n_tiles + out.regions - 1) / out.regions;
 	return launch_hash_any(a, out, bin_shift, sd, fr.dyn, query, fr.small, s);

@@ -266,6 +266,82 @@ __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, u
 	return mis;
 }
 
+// Read-grid staging (pass A, uniform layout, tiles of whole reads starting at g0): source byte x of the tile
+// (read x / L, base x % L) goes to LDS byte (x / L) * lpad + x % L, so every read starts on an 8-byte boundary
+// and the pad bytes between reads (zeroed once by the kernel, never written) end every window that would run
+// over a read's end.  Same staged byte as seq_stage_convert (code << 4 | valid | good, `good` cleared on a
+// read's first base).  The caller provides the barriers.
+template <int NT, int KW>
+__device__ __forceinline__ void seq_stage_convert_grid(const StageRaw<KW>& pre, uint8_t* tile, SeqShared& sh,
+                                                       const uint8_t* seq, uint64_t len, uint32_t L, uint32_t lpad,
+                                                       uint32_t tile_bytes, uint64_t g0)
+{
+	uint32_t tid = threadIdx.x; // laundered: see seq_stage_convert
+	asm volatile("" : "+v"(tid));
+	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(seq + g0) & 3);
+	uint64_t need64 = len > g0 ? len - g0 : 0;
+	const uint32_t need = need64 > tile_bytes ? tile_bytes : (uint32_t)need64;
+	const uint32_t inv = 0xffffffffu / L;
+	const bool halves = mis == 0 && (L & 1) == 0; // every aligned byte pair of the source lies inside one read
+#pragma unroll
+	for (int a = 0; a < KW / 4 + 1; ++a) {
+		const uint32_t j = tid + (uint32_t)a * NT;
+		const int32_t rel0 = (int32_t)(4 * j) - (int32_t)mis; // tile offset of the word's first byte
+		if (rel0 >= (int32_t)tile_bytes)
+			continue;
+		const uint32_t raw = pre.w[a];
+		const uint32_t idx = (raw >> 1) & 0x03030303u;
+		uint32_t o;
+		if ((raw & 0xdfdfdfdfu) == __builtin_amdgcn_perm(0u, 0x47544341u, idx))
+			o = __builtin_amdgcn_perm(0u, 0x23331303u, idx);
+		else
+			o = (uint32_t)sh.lut[raw & 0xff] | ((uint32_t)sh.lut[(raw >> 8) & 0xff] << 8) |
+			    ((uint32_t)sh.lut[(raw >> 16) & 0xff] << 16) | ((uint32_t)sh.lut[raw >> 24] << 24);
+		// bytes past the data are staged as zeros (no stale flags), bytes before the tile are not staged
+		const int32_t left = (int32_t)need - rel0;
+		if (left < 4)
+			o &= left <= 0 ? 0u : (1u << (8 * left)) - 1;
+		const uint32_t x0 = rel0 < 0 ? 0u : (uint32_t)rel0;
+		uint32_t q = __umulhi(x0, inv), p = x0 - q * L;
+		while (p >= L) {
+			p -= L;
+			++q;
+		}
+		uint32_t dst = q * lpad + p;
+		if (halves) {
+			uint32_t h0 = o & 0xffffu, h1 = o >> 16;
+			if (p == 0)
+				h0 &= ~kBaseGood;
+			*reinterpret_cast<uint16_t*>(tile + dst) = (uint16_t)h0;
+			p += 2;
+			dst += 2;
+			if (p >= L) { // == L: the second pair opens the next read
+				p = 0;
+				dst += lpad - L;
+				h1 &= ~kBaseGood;
+			}
+			*reinterpret_cast<uint16_t*>(tile + dst) = (uint16_t)h1;
+		} else {
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				const int32_t x = rel0 + b;
+				if (x < 0 || x >= (int32_t)tile_bytes)
+					continue;
+				uint32_t e = (o >> (8 * b)) & 0xffu;
+				if (p == 0)
+					e &= ~kBaseGood;
+				tile[dst] = (uint8_t)e;
+				++p;
+				++dst;
+				if (p == L) {
+					p = 0;
+					dst += lpad - L;
+				}
+			}
+		}
+	}
+}
+
 // load + convert in one go (the direct kernels)
 template <int NT, int KW = kW, bool LEAD_BARRIER = true, bool TRAIL_BARRIER = true>
 __device__ __forceinline__ uint32_t seq_stage_tile(uint8_t* tile, uint32_t tile_cap, SeqShared& sh,

@@ -256,8 +256,15 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 		const uint64_t ob = (g0 >> 3) + tid;
 		if (OP == OP_BF_CONTAINS || OP == OP_BF_INSERT_CHECK || OP == OP_CBF_QUERY || OP == OP_BF_RESOLVE ||
 		    OP == OP_BF_CONTAINS_WIN) {
-			if (a.hit_bits && ob < out_bytes)
-				a.hit_bits[ob] = (uint8_t)hit_mask;
+			if (a.hit_bits && ob < out_bytes) {
+				// the resolve step only ever CLEARS windows: its tile range may reach back into windows an
+				// earlier batch of the partitioned query has already resolved (batches of pass-A tiles need
+				// not end on this kernel's tile boundaries), and those answers stand
+				if (OP == OP_BF_RESOLVE)
+					a.hit_bits[ob] &= (uint8_t)hit_mask;
+				else
+					a.hit_bits[ob] = (uint8_t)hit_mask;
+			}
 		}
 		if (a.valid_bits && ob < out_bytes)
 			a.valid_bits[ob] = (uint8_t)valid_mask;

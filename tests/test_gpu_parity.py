@@ -649,6 +649,40 @@ def test_partitioned_query_equals_direct(bf, bits, miss_reads):
     assert (hit.cpu().numpy()[:nb] == out["direct"][0][:nb]).all() and (valid.cpu().numpy()[:nb] == out["direct"][1][:nb]).all()
 
 
+@pytest.mark.parametrize("L,k", [(150, 31), (100, 31), (151, 25), (50, 33), (250, 33), (152, 21)])
+def test_partitioned_many_batches_read_grid_equals_direct(bf, L, k):
+    """pass A's read grid (tiles of whole reads) with a scratch cap that forces many batches: batch boundaries
+    do not fall on the resolve kernel's tile boundaries, and a later batch's resolve step must not undo an
+    earlier one's answers (it did, once: found by tools/fuzz_parity.py); odd L takes the byte-wise staging"""
+    import torch
+
+    h, bits, n = 3, 1 << 31, 120000
+    rng = np.random.default_rng(L * 131 + k)
+    a = rng.choice(np.frombuffer(b"ACGTacgt", np.uint8), size=(n, L))
+    a[rng.random((n, L)) < 0.0005] = ord("N")
+    flat = torch.from_numpy(a.reshape(-1).copy()).cuda()
+    q = flat.clone()
+    idx = np.flatnonzero(rng.random(n) < 0.05)  # 5 % foreign reads: failures in every batch, within the fail list
+    q.view(n, L)[torch.from_numpy(idx).cuda()] = torch.from_numpy(
+        rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(idx.size, L))).cuda()
+    res = []
+    for mode in ("direct", "partitioned"):
+        f = bf.BloomFilter(bits, h, k)
+        f.setInsertMode(mode, scratch_bytes=(256 << 20) if mode == "partitioned" else 0)
+        f.setQueryMode(mode)
+        f.setProfiling(True)
+        f.insertSeqs(flat, read_len=L)
+        hit, valid, cnt = f.containsSeqs(q, read_len=L, want_counts=True)
+        torch.cuda.synchronize()
+        if mode == "partitioned":
+            prof = f.getProfile()
+            assert prof["insert_hash"][1] >= 2 and prof["query_hash"][1] >= 2  # several batches each
+        res.append((f, hit.cpu().numpy(), valid.cpu().numpy(), cnt.tolist()))
+    assert res[1][0].compare(res[0][0]) == (0, 0, 0)
+    assert (res[0][2] == res[1][2]).all() and (res[0][1] == res[1][1]).all() and res[0][3] == res[1][3]
+    assert 0 < res[0][3][1] < res[0][3][0]
+
+
 # ---------------------------------------------------------------------------------------------
 # btlbf_clear is lazy (and a new filter is a cleared filter): the first partitioned insert builds every
 # segment from zero in LDS; every other entry point must see the zeros
