@@ -1124,6 +1124,26 @@ namespace {
 static constexpr uint64_t kFailCap = 4ull << 20;          // entries
 static constexpr uint64_t kFailTableSlots = 2 * kFailCap; // power of two
 static constexpr uint64_t kFailBytes = 256 + kFailCap * 8 + kFailTableSlots * 8;
+// entries a FRESH insert batch (partitioned_insert) may report as explicit positions instead of staging them
+static constexpr uint64_t kFreshSpillCap = 16ull << 20;
+
+// The tail of the partition scratch: a query's fail list + failed-position table, or a fresh insert's spill list.
+// Inserts (fresh or not) and queries reserve the same tail, so that alternating between them never changes the
+// scratch size (a re-allocation of ~100 GB costs seconds); a caller-imposed budget below 2 GiB gets short lists
+// (more than a list holds and the batch is redone the plain way, which is always correct).
+struct PartTail {
+	uint64_t fail_cap, table_slots, spill_cap, bytes;
+};
+static PartTail part_tail(uint64_t budget)
+{
+	PartTail t;
+	const bool full = budget >= (2ull << 30);
+	t.fail_cap = full ? kFailCap : 256ull << 10;
+	t.spill_cap = full ? kFreshSpillCap : 512ull << 10;
+	t.table_slots = 2 * t.fail_cap;
+	t.bytes = std::max<uint64_t>(256 + t.fail_cap * 8 + t.table_slots * 8, 256 + t.spill_cap * 8);
+	return t;
+}
 
 // one partition level: bins of 2^shift positions, written as regions of `cap` chunks
 struct PartLevel {
@@ -1364,7 +1384,7 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 
 // plan the single-GPU pipeline for a buffer and (re)allocate the scratch;
 // *ok = false means "not applicable, use the direct kernel"
-int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, PartPlan& pl, PartTiling* tiling,
+int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan& pl, PartTiling* tiling,
                  uint8_t** extra, bool* ok)
 {
 	*ok = false;
@@ -1391,6 +1411,8 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, Par
 		return BTLBF_OK;
 	*tiling = part_tiling(f->hp, l0.P, base.layout, base.len);
 	const uint64_t budget = scratch_budget(f);
+	*tail = part_tail(budget);
+	const uint64_t extra_bytes = tail->bytes;
 	// a shard fed every rank's reads (ShardedBloomFilter's gather mode) keeps only its window's share
 	const double ppt = probes_per_tile(f, *tiling) * ((double)f->mod.shard_len / (double)f->mod.size);
 	uint64_t tiles = tiling->n_tiles;
@@ -1413,11 +1435,6 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, uint64_t extra_bytes, Par
 	return BTLBF_OK;
 }
 
-// entries a FRESH batch (below) may report as explicit positions instead of staging them
-static constexpr uint64_t kFreshSpillCap = 16ull << 20;
-// inserts (fresh or not) and queries reserve the same tail of the scratch, so that alternating between them
-// never changes the scratch size (a re-allocation of ~100 GB costs seconds)
-static constexpr uint64_t kPartExtraBytes = std::max<uint64_t>(kFailBytes, 256 + kFreshSpillCap * 8);
 
 int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* done)
 {
@@ -1431,7 +1448,8 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 	PartTiling tiling;
 	uint8_t* extra = nullptr;
 	bool ok = false;
-	int rc = part_prepare(f, base, kPartExtraBytes, pl, &tiling, &extra, &ok);
+	PartTail tail;
+	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok);
 	if (rc || !ok)
 		return rc;
 	const uint64_t total_tiles = tiling.n_tiles;
@@ -1449,7 +1467,7 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 				sd.pos_base = f->mod.shard_lo;
 				sd.spill_count = reinterpret_cast<unsigned long long*>(extra);
 				sd.spill_list = reinterpret_cast<uint64_t*>(extra + 256);
-				sd.spill_cap = kFreshSpillCap;
+				sd.spill_cap = tail.spill_cap;
 				HIP_TRY(hipMemsetAsync(sd.spill_count, 0, 8, s));
 			}
 			{
@@ -1464,7 +1482,7 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 			unsigned long long n_spill = 0;
 			HIP_TRY(hipMemcpyAsync(&n_spill, sd.spill_count, 8, hipMemcpyDeviceToHost, s));
 			HIP_TRY(hipStreamSynchronize(s));
-			if (n_spill <= kFreshSpillCap) {
+			if (n_spill <= tail.spill_cap) {
 				PartSide plain;
 				memset(&plain, 0, sizeof plain);
 				plain.counting = sd.counting;
@@ -1481,7 +1499,7 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 // hit_bits := hit_bits with the windows owning a failed position cleared, for seq tiles
 // [first, first+n) of the direct kernels' tiling
 int resolve_range(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, const uint64_t* fail_list, uint64_t n_fail,
-                  uint64_t* table, uint64_t first, uint64_t n, hipStream_t s)
+                  uint64_t* table, uint64_t max_slots, uint64_t first, uint64_t n, hipStream_t s)
 {
 	SeqArgs d = base;
 	d.first_tile = first;
@@ -1492,7 +1510,7 @@ int resolve_range(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, const
 	// the table is sized to the set (load <= 1/4): a few thousand failed positions make a table that stays in
 	// L2, and every probe of every window of the range is looked up in it
 	uint64_t slots = 1024;
-	while (slots < 4 * n_fail && slots < kFailTableSlots)
+	while (slots < 4 * n_fail && slots < max_slots)
 		slots <<= 1;
 	HIP_TRY(hipMemsetAsync(table, 0, slots * 8, s));
 	HIP_TRY(launch_failset_build(fail_list, n_fail, table, slots - 1, s));
@@ -1516,7 +1534,8 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	PartTiling tiling;
 	uint8_t* extra = nullptr;
 	bool ok = false;
-	int rc = part_prepare(f, base, kPartExtraBytes, pl, &tiling, &extra, &ok);
+	PartTail tail;
+	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok);
 	if (rc || !ok)
 		return rc;
 	const uint64_t total_tiles = tiling.n_tiles;
@@ -1524,12 +1543,12 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	memset(&sd, 0, sizeof sd);
 	sd.fail_count = reinterpret_cast<unsigned long long*>(extra);
 	sd.fail_list = reinterpret_cast<uint64_t*>(extra + 256);
-	sd.fail_cap = kFailCap;
+	sd.fail_cap = tail.fail_cap;
 	sd.counting = f->kind == BTLBF_COUNTING8;
 	sd.threshold = f->thr;
 	sd.pos_base = f->mod.shard_lo; // the fail set is keyed by global position
 	const int direct_op = sd.counting ? OP_CBF_QUERY : f->shard_count != 1 ? OP_BF_CONTAINS_WIN : OP_BF_CONTAINS;
-	uint64_t* table = sd.fail_list + kFailCap;
+	uint64_t* table = sd.fail_list + tail.fail_cap;
 	if (counts)
 		HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
 	const uint64_t seq_tw = (uint64_t)seq_tile_windows();
@@ -1560,7 +1579,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 		const uint64_t end_b = std::min<uint64_t>(base.len, (t0 + a.n_tiles) * (uint64_t)tiling.tile_bytes);
 		const uint64_t n = std::min<uint64_t>((end_b + seq_tw - 1) / seq_tw, seq_tiles_all) - first;
 		ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
-		if (n_fail > kFailCap) {
+		if (n_fail > tail.fail_cap) {
 			SeqArgs d = base;
 			d.first_tile = first;
 			d.n_tiles = n;
@@ -1568,7 +1587,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 			d.valid_bits = nullptr;
 			d.counts = nullptr;
 			HIP_TRY(launch_seq_op(direct_op, d, s));
-		} else if ((rc = resolve_range(f, base, hit_bits, sd.fail_list, n_fail, table, first, n, s))) {
+		} else if ((rc = resolve_range(f, base, hit_bits, sd.fail_list, n_fail, table, tail.table_slots, first, n, s))) {
 			return rc;
 		}
 	}
@@ -2102,7 +2121,7 @@ extern "C" int btlbf_resolve_seqs(btlbf_filter* f, const char* seq, uint64_t len
 	SeqArgs a = base_args(f, v, len);
 	fill_mod(a.mod, f->mod.size, 0, f->mod.size); // global positions
 	return resolve_range(f, a, reinterpret_cast<uint8_t*>(hit_bits), fail_list, n_fail,
-	                     static_cast<uint64_t*>(f->d_part), 0, 0, s);
+	                     static_cast<uint64_t*>(f->d_part), kFailTableSlots, 0, 0, s);
 }
 
 namespace {

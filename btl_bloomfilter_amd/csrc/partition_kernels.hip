@@ -289,14 +289,25 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 			}
 #pragma unroll
 			for (int u = 0; u < kEntU; ++u) {
-				if (left[u] > 0)
-					apply_entry<MODE>(lds, q[u].x, sd, seg_base);
-				if (left[u] > 1)
-					apply_entry<MODE>(lds, q[u].y, sd, seg_base);
-				if (left[u] > 2)
-					apply_entry<MODE>(lds, q[u].z, sd, seg_base);
-				if (left[u] > 3)
-					apply_entry<MODE>(lds, q[u].w, sd, seg_base);
+				if (MODE < APPLY_CNT_INC) {
+					// bit filter: a region's last vector is padded with copies of its last entry (part_finish),
+					// and a repeated position changes nothing for OR / test -- whole vectors, one test
+					if (left[u] > 0) {
+						apply_entry<MODE>(lds, q[u].x, sd, seg_base);
+						apply_entry<MODE>(lds, q[u].y, sd, seg_base);
+						apply_entry<MODE>(lds, q[u].z, sd, seg_base);
+						apply_entry<MODE>(lds, q[u].w, sd, seg_base);
+					}
+				} else {
+					if (left[u] > 0)
+						apply_entry<MODE>(lds, q[u].x, sd, seg_base);
+					if (left[u] > 1)
+						apply_entry<MODE>(lds, q[u].y, sd, seg_base);
+					if (left[u] > 2)
+						apply_entry<MODE>(lds, q[u].z, sd, seg_base);
+					if (left[u] > 3)
+						apply_entry<MODE>(lds, q[u].w, sd, seg_base);
+				}
 				q[u] = nq[u];
 				left[u] = nleft[u];
 			}
