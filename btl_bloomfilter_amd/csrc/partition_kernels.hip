@@ -140,6 +140,7 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 // position reported for failed tests
 // Input bin blockIdx.x holds the entries of segment seg_first + blockIdx.x (group-relative numbering).
 static constexpr uint32_t kApplyMaxRegions = 1024; // region table kept in LDS (more: plain loop)
+static constexpr uint32_t kApplyFewRegions = 16;    // up to here the regions are walked one by one (uniform control flow)
 
 // what pass C does with an entry (= position inside the segment held in LDS)
 enum ApplyMode : int {
@@ -249,7 +250,46 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 			dst = reinterpret_cast<const uint4*>(in.ent + (uint64_t)r_reg[wr[u]] * cap_entries)[wi[u]];        \
 		}                                                                                                      \
 	} while (0)
-	if (tabled) {
+	// FEW regions (the usual case behind a split pass: one region per slice): they are walked one after the
+	// other, kFewU vectors per thread and trip, with control flow that is uniform over the workgroup (region
+	// sizes are read into scalar registers) -- an address and a load per vector instead of a per-lane search
+	// for "which region is my vector in".  The next trip is requested before the current one is applied.
+	constexpr int kFewU = 3;
+	const bool few = tabled && n_regions <= kApplyFewRegions;
+	uint4 fq[kFewU];
+	uint32_t fl[kFewU];
+	uint32_t f_r = 0, f_trip = 0; // next (region, trip) to request
+	auto few_skip = [&]() {
+		while (f_r < n_regions &&
+		       f_trip * (uint32_t)(kFewU * NT * 4) >= (uint32_t)__builtin_amdgcn_readfirstlane((int)r_n[f_r])) {
+			++f_r;
+			f_trip = 0;
+		}
+	};
+	auto few_request = [&](uint4 (&d)[kFewU], uint32_t (&lf)[kFewU]) {
+		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_n[f_r]);
+		const uint32_t reg = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_reg[f_r]);
+		const uint4* src = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg * cap_entries);
+#pragma unroll
+		for (int u = 0; u < kFewU; ++u) {
+			const uint32_t i = (f_trip * kFewU + (uint32_t)u) * NT + tid;
+			lf[u] = 0;
+			d[u] = make_uint4(0, 0, 0, 0);
+			if (i * 4 < n) {
+				d[u] = src[i];
+				lf[u] = n - i * 4;
+			}
+		}
+		++f_trip;
+		few_skip();
+	};
+	bool few_have = false;
+	if (few) {
+		few_skip();
+		few_have = f_r < n_regions;
+		if (few_have)
+			few_request(fq, fl);
+	} else if (tabled) {
 #pragma unroll
 		for (int u = 0; u < kEntU; ++u) {
 			wr[u] = 0;
@@ -277,7 +317,40 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 	}
 	__syncthreads();
 	uint32_t* lds = reinterpret_cast<uint32_t*>(dyn);
-	if (tabled) {
+	if (few) {
+		while (few_have) {
+			uint4 nq[kFewU];
+			uint32_t nl[kFewU];
+			const bool more = f_r < n_regions;
+			if (more)
+				few_request(nq, nl);
+#pragma unroll
+			for (int u = 0; u < kFewU; ++u) {
+				if (MODE < APPLY_CNT_INC) {
+					if (fl[u] > 0) { // whole vectors: see below
+						apply_entry<MODE>(lds, fq[u].x, sd, seg_base);
+						apply_entry<MODE>(lds, fq[u].y, sd, seg_base);
+						apply_entry<MODE>(lds, fq[u].z, sd, seg_base);
+						apply_entry<MODE>(lds, fq[u].w, sd, seg_base);
+					}
+				} else {
+					if (fl[u] > 0)
+						apply_entry<MODE>(lds, fq[u].x, sd, seg_base);
+					if (fl[u] > 1)
+						apply_entry<MODE>(lds, fq[u].y, sd, seg_base);
+					if (fl[u] > 2)
+						apply_entry<MODE>(lds, fq[u].z, sd, seg_base);
+					if (fl[u] > 3)
+						apply_entry<MODE>(lds, fq[u].w, sd, seg_base);
+				}
+				if (more) {
+					fq[u] = nq[u];
+					fl[u] = nl[u];
+				}
+			}
+			few_have = more;
+		}
+	} else if (tabled) {
 		while (left[0]) {
 			uint4 nq[kEntU];
 			uint32_t nleft[kEntU];
