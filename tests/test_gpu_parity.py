@@ -683,6 +683,39 @@ def test_partitioned_many_batches_read_grid_equals_direct(bf, L, k):
     assert 0 < res[0][3][1] < res[0][3][0]
 
 
+@pytest.mark.parametrize("L,k,mis", [(150, 31, 1), (150, 31, 2), (151, 31, 0), (151, 21, 3), (64, 31, 5), (100, 64, 6)])
+def test_read_grid_misaligned_buffers_and_odd_read_lengths(bf, L, k, mis):
+    """the read grid's staging scatters bytes pairwise only for even L on a 4-byte aligned buffer; every other
+    case goes byte by byte -- partitioned == direct (bodies, hit and valid bitmaps) on misaligned device pointers"""
+    import torch
+
+    h, bits, n = 4, 1 << 30, 70000
+    rng = np.random.default_rng(L + 7 * k + mis)
+    a = rng.choice(np.frombuffer(b"ACGTacgt", np.uint8), size=(n, L))
+    a[rng.random((n, L)) < 0.001] = ord("N")
+    t = torch.zeros(n * L + 16, dtype=torch.uint8, device="cuda")
+    t[mis:mis + n * L] = torch.from_numpy(a.reshape(-1).copy()).cuda()
+    buf = t[mis:mis + n * L]
+    q = torch.zeros(n * L + 16, dtype=torch.uint8, device="cuda")
+    q[mis:mis + n * L] = buf
+    qv = q[mis:mis + n * L]
+    idx = np.flatnonzero(rng.random(n) < 0.02)
+    qv.view(n, L)[torch.from_numpy(idx).cuda()] = torch.from_numpy(
+        rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(idx.size, L))).cuda()
+    res = []
+    for mode in ("direct", "partitioned"):
+        f = bf.BloomFilter(bits, h, k)
+        f.setInsertMode(mode)
+        f.setQueryMode(mode)
+        f.insertSeqs(buf, read_len=L)
+        hit, valid, cnt = f.containsSeqs(qv, read_len=L, want_counts=True)
+        torch.cuda.synchronize()
+        res.append((f, hit.cpu().numpy(), valid.cpu().numpy(), cnt.tolist()))
+    assert res[1][0].compare(res[0][0]) == (0, 0, 0)
+    assert (res[0][2] == res[1][2]).all() and (res[0][1] == res[1][1]).all() and res[0][3] == res[1][3]
+    assert 0 < res[0][3][1] < res[0][3][0]
+
+
 # ---------------------------------------------------------------------------------------------
 # btlbf_clear is lazy (and a new filter is a cleared filter): the first partitioned insert builds every
 # segment from zero in LDS; every other entry point must see the zeros
