@@ -491,12 +491,10 @@ __global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, ui
 	bool cold = false;
 	if (r < n_reads) {
 		const uint8_t* rd = seq + r * L;
-		const uint32_t offs[3] = {0, W / 2, W - 1};
-		uint32_t clean = 0, misses = 0;
-		for (int sidx = 0; sidx < 3; ++sidx) {
-			if (sidx && offs[sidx] == offs[sidx - 1])
-				continue;
-			const uint8_t* w = rd + offs[sidx];
+		// one sample = full contains() of the window at `off`: all h probes are requested at once (no early exit
+		// inside a sample: one memory latency, not h of them); 0 = unclean window, 1 = miss, 2 = hit
+		auto sample = [&](uint32_t off) -> uint32_t {
+			const uint8_t* w = rd + off;
 			uint64_t fh = 0, rh = 0;
 			uint32_t ok = kBaseValid;
 			uint32_t i = 0;
@@ -526,19 +524,32 @@ __global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, ui
 				rh = sror1(rh) ^ tab[e >> kCodeShift][1];
 			}
 			if (!(ok & kBaseValid))
-				continue;
-			++clean;
+				return 0;
 			const uint64_t b = rh < fh ? rh : fh;
 			bool hit = true;
-			for (uint32_t j = 0; j < hp.h && hit; ++j) {
+			for (uint32_t j = 0; j < hp.h; ++j) {
 				const uint64_t hv = j ? extra_hash(b, hp.kms, j) : b;
 				const uint64_t p = mod.pow2 ? (hv & mod.mask) : reduce_mod<false>(hv, mod);
 				if (counting)
-					hit = cbf_read_fresh(static_cast<const uint32_t*>(filter), p) >= threshold;
+					hit &= cbf_read_fresh(static_cast<const uint32_t*>(filter), p) >= threshold;
 				else
-					hit = (bf_word(static_cast<const uint32_t*>(filter), p) >> (p & 31)) & 1u;
+					hit &= (bool)((bf_word(static_cast<const uint32_t*>(filter), p) >> (p & 31)) & 1u);
 			}
-			misses += !hit;
+			return hit ? 2u : 1u;
+		};
+		// The majority rule matters for the WARM side: a foreign read that slipped into the warm buffer on one
+		// false-positive sample would put failures into the partitioned query and cost it a resolve pass over
+		// everything; two false positives in one read do not happen.  The third sample is only looked at when the
+		// first two disagree (or one of them was unclean).
+		uint32_t clean = 0, misses = 0;
+		const uint32_t s0 = sample(0);
+		const uint32_t s1 = W / 2 != 0 ? sample(W / 2) : 0;
+		clean += (s0 != 0) + (s1 != 0);
+		misses += (s0 == 1) + (s1 == 1);
+		if (!(s0 == s1 && s0 != 0) && W - 1 != W / 2) {
+			const uint32_t s2 = sample(W - 1);
+			clean += s2 != 0;
+			misses += s2 == 1;
 		}
 		cold = clean > 0 && 2 * misses > clean;
 	}
