@@ -144,8 +144,9 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 				// tile's bitmap; the partition round below has the barriers) and written out whole afterwards
 				uint32_t* bm = grid_bm + ((t - t_begin) & 1) * grid_bm_words;
 				const uint32_t sh5 = grid_bit & 31;
-				atomicOr(&bm[grid_bit >> 5], vmask << sh5);
-				if (sh5 > 24)
+				if (vmask << sh5)
+					atomicOr(&bm[grid_bit >> 5], vmask << sh5);
+				if (sh5 > 24 && (vmask >> (32 - sh5))) // (never beyond the bitmap: bits past a read's last window are 0)
 					atomicOr(&bm[(grid_bit >> 5) + 1], vmask >> (32 - sh5));
 			}
 			const int w4 = w % kPartHalf;
