@@ -60,6 +60,8 @@ def one_case(rng, it):
         if idx.size:
             q.view(n_reads, L)[torch.from_numpy(idx).cuda()] = torch.from_numpy(rand_reads(rng, idx.size, L, 0.001)).cuda()
     res = []
+    stateful = rng.random() < 0.3 and flat.numel() < 12_000_000
+    rng_state = int(rng.integers(0, 1 << 30))
     for mode in ("direct", "partitioned", "auto"):
         if counting:
             f = m.CountingBloomFilter(max(bits // 8, 64), h, k, thr)
@@ -77,17 +79,42 @@ def one_case(rng, it):
             f.insertSeqs(flat, **kw)
         hit, valid, cnt = f.containsSeqs(q, want_counts=True, **kw)
         torch.cuda.synchronize()
-        res.append((f.download().copy(), hit.cpu().numpy().copy(), cnt.tolist(), thr, valid.cpu().numpy().copy()))
+        body = f.download().copy()
+        extra = None
+        if stateful:
+            # the same filter goes on: a second (not fresh) insert, a clear (lazy), an insert of the query reads
+            # (fresh again), a query of the first reads
+            if counting:
+                f.insertSeqs(q, increment_all=True, **kw)
+            else:
+                f.insertSeqs(q, **kw)
+            b2 = f.download().copy()
+            f.clear()
+            if rng_state % 2:
+                assert not f.download().any()  # something that must see the cleared array
+            if counting:
+                f.insertSeqs(q, increment_all=True, **kw)
+            else:
+                f.insertSeqs(q, **kw)
+            h3, v3, c3 = f.containsSeqs(flat, want_counts=True, **kw)
+            torch.cuda.synchronize()
+            extra = (b2, f.download().copy(), h3.cpu().numpy().copy(), c3.tolist())
+        res.append((body, hit.cpu().numpy().copy(), cnt.tolist(), thr, valid.cpu().numpy().copy(), extra))
         f.releaseScratch()
         del f
     a, b, c = res
     same = [bool((a[0] == b[0]).all()), bool((a[1] == b[1]).all()), a[2] == b[2], bool((a[4] == b[4]).all()),
             bool((a[0] == c[0]).all()), bool((a[1] == c[1]).all()), a[2] == c[2], bool((a[4] == c[4]).all())]
+    if stateful:
+        for o in (b, c):
+            same += [bool((a[5][0] == o[5][0]).all()), bool((a[5][1] == o[5][1]).all()),
+                     bool((a[5][2] == o[5][2]).all()), a[5][3] == o[5][3]]
     ok = all(same)
     desc = dict(it=it, bits=bits, k=k, h=h, L=L, n_reads=n_reads, counting=bool(counting), ragged=bool(ragged), scratch=scratch,
-                spaced=bool(seeds))
+                spaced=bool(seeds), stateful=bool(stateful))
     if not ok:
-        print("MISMATCH (filter, hits, counts, valid) x (partitioned, auto) =", same, desc, a[2], b[2], c[2], flush=True)
+        print("MISMATCH (filter, hits, counts, valid) x (partitioned, auto) [+ stateful leg: body2, body3, hits3, counts3 x 2] =",
+              same, desc, a[2], b[2], c[2], flush=True)
     return ok, desc
 
 
