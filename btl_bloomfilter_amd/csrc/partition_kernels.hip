@@ -258,29 +258,50 @@ __global__ __launch_bounds__(NT) void part_apply_kernel(uint8_t* filter, uint64_
 	const bool few = tabled && n_regions <= kApplyFewRegions;
 	uint4 fq[kFewU];
 	uint32_t fl[kFewU];
-	uint32_t f_r = 0, f_trip = 0; // next (region, trip) to request
-	auto few_skip = [&]() {
-		while (f_r < n_regions &&
-		       f_trip * (uint32_t)(kFewU * NT * 4) >= (uint32_t)__builtin_amdgcn_readfirstlane((int)r_n[f_r])) {
+	// next vector to request: vector f_off of region f_r.  A trip takes kFewU * NT consecutive vectors and may
+	// run over the end of its region into the NEXT one (not further), so the trips stay full whatever the
+	// region sizes are.
+	uint32_t f_r = 0, f_off = 0;
+	auto few_nvec = [&](uint32_t r) -> uint32_t {
+		return ((uint32_t)__builtin_amdgcn_readfirstlane((int)r_n[r]) + 3) / 4;
+	};
+	auto few_skip = [&]() { // -> a region with vectors left, or f_r == n_regions
+		while (f_r < n_regions && f_off >= few_nvec(f_r)) {
 			++f_r;
-			f_trip = 0;
+			f_off = 0;
 		}
 	};
 	auto few_request = [&](uint4 (&d)[kFewU], uint32_t (&lf)[kFewU]) {
-		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_n[f_r]);
-		const uint32_t reg = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_reg[f_r]);
-		const uint4* src = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg * cap_entries);
+		const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_n[f_r]), nv0 = (n0 + 3) / 4;
+		const uint32_t reg0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_reg[f_r]);
+		const bool two = f_r + 1 < n_regions;
+		const uint32_t n1 = two ? (uint32_t)__builtin_amdgcn_readfirstlane((int)r_n[two ? f_r + 1 : f_r]) : 0u, nv1 = (n1 + 3) / 4;
+		const uint32_t reg1 = two ? (uint32_t)__builtin_amdgcn_readfirstlane((int)r_reg[two ? f_r + 1 : f_r]) : reg0;
+		const uint4* src0 = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg0 * cap_entries);
+		const uint4* src1 = reinterpret_cast<const uint4*>(in.ent + (uint64_t)reg1 * cap_entries);
 #pragma unroll
 		for (int u = 0; u < kFewU; ++u) {
-			const uint32_t i = (f_trip * kFewU + (uint32_t)u) * NT + tid;
+			const uint32_t v = f_off + (uint32_t)u * NT + tid; // vector index counted from the start of region f_r
 			lf[u] = 0;
 			d[u] = make_uint4(0, 0, 0, 0);
-			if (i * 4 < n) {
-				d[u] = src[i];
-				lf[u] = n - i * 4;
+			if (v < nv0) {
+				d[u] = src0[v];
+				lf[u] = n0 - v * 4;
+			} else if (v - nv0 < nv1) {
+				d[u] = src1[v - nv0];
+				lf[u] = n1 - (v - nv0) * 4;
 			}
 		}
-		++f_trip;
+		const uint32_t end = f_off + (uint32_t)(kFewU * NT);
+		if (end <= nv0) {
+			f_off = end;
+		} else if (two && end - nv0 <= nv1) {
+			++f_r;
+			f_off = end - nv0;
+		} else { // the trip ended with region f_r + 1 (or there is none)
+			f_r += 2;
+			f_off = 0;
+		}
 		few_skip();
 	};
 	bool few_have = false;
