@@ -103,6 +103,7 @@ _PROTOS = {
     "btlbf_route_plan": (C.c_int, [_P, C.c_uint64, C.POINTER(Layout), C.c_uint, C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64)]),
     "btlbf_route_windows": (C.c_int, [_P, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "btlbf_plan_read_grid": (C.c_int, [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint32)]),
     "btlbf_route_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_uint64, C.c_uint, C.c_uint, C.c_int, _P, _P,
                                    _P, _P, _P, _P, C.c_uint64, _P, _P]),
     "btlbf_route_geometry": (C.c_int, [_P, C.c_uint64, C.POINTER(Layout), C.c_uint, C.c_uint, C.POINTER(C.c_uint32)]),

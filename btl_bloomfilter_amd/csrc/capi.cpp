@@ -1897,6 +1897,23 @@ extern "C" int btlbf_route_plan(btlbf_filter* f, uint64_t len, const btlbf_layou
 	return BTLBF_OK;
 }
 
+// planning only (no device needed): the read grid pass A would use for fixed-length reads
+extern "C" int btlbf_plan_read_grid(unsigned kmer_size, unsigned hash_num, unsigned read_len, unsigned level0_bins,
+                                    uint32_t* out4)
+{
+	if (!out4 || kmer_size == 0 || hash_num == 0 || level0_bins == 0 || level0_bins > 1024)
+		return fail(BTLBF_EINVAL, "btlbf_plan_read_grid: bad argument");
+	HashParams hp;
+	fill_hash_params(hp, kmer_size, hash_num);
+	PartGrid g;
+	(void)part_read_grid(hp, level0_bins, LayoutParams{nullptr, 0, read_len}, &g);
+	out4[0] = g.reads;
+	out4[1] = g.gpr;
+	out4[2] = g.lpad;
+	out4[3] = g.cap;
+	return BTLBF_OK;
+}
+
 extern "C" int btlbf_route_windows(btlbf_filter* f, unsigned n_shards, unsigned* n_windows,
                                    unsigned* shards_per_window)
 {

@@ -342,6 +342,13 @@ int btlbf_apply_spill(btlbf_filter* f, const uint64_t* global_pos, uint64_t n, i
 int btlbf_resolve_seqs(btlbf_filter* f, const char* seq, uint64_t len, const btlbf_layout* layout,
                        const uint64_t* fail_list, uint64_t n_fail, uint64_t* hit_bits, void* stream);
 
+/* Planning only, no device needed: the READ GRID pass A of the partitioned pipeline uses for fixed-length reads of
+   read_len bases with `level0_bins` level-0 bins: out4 = { reads per tile, groups of 8
+   window starts per read, bytes a read occupies in the LDS tile, bytes of LDS the tile image takes }; all zero
+   when plain tiles are used instead (ragged input, reads too short / too long, no gain). */
+int btlbf_plan_read_grid(unsigned kmer_size, unsigned hash_num, unsigned read_len, unsigned level0_bins,
+                         uint32_t* out4);
+
 /* number of set bits in a device buffer of nbytes (multiple of 8, e.g. a hit bitmap); synchronises the stream */
 int btlbf_popcount_bits(const void* dev_buf, uint64_t nbytes, uint64_t* out, int device, void* stream);
 

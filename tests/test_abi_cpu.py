@@ -67,3 +67,36 @@ def test_product_never_references_the_oracle():
                     if re.search(r"(from|import)\s+oracle|btl_oracle|libbtlref|pyoracle", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_read_grid_plan_invariants(lib):
+    """pass A's read grid (planning is host code, no GPU needed): whole reads per tile, whole bytes of the window
+    bitmaps per tile, every lane inside the workgroup, the tile image inside the LDS, and only where it pays"""
+    import ctypes as C
+
+    out = (C.c_uint32 * 4)()
+    used = 0
+    for k in (5, 21, 25, 31, 32, 33, 47, 64, 96, 150):
+        for L in (k, k + 1, 40, 50, 64, 75, 100, 101, 125, 150, 151, 152, 200, 250, 251, 300, 500, 1000, 5000):
+            if L < k:
+                continue
+            for bins in (64, 512, 1024):
+                assert lib.btlbf_plan_read_grid(k, 4, L, bins, out) == 0
+                reads, gpr, lpad, cap = list(out)
+                if reads == 0:
+                    assert (gpr, lpad, cap) == (0, 0, 0)
+                    continue
+                used += 1
+                wins = L - k + 1
+                assert gpr == (wins + 7) // 8 and lpad == (L + 7) // 8 * 8
+                assert reads * gpr <= 1024                      # one lane per group of 8 window starts
+                assert (reads * L) % 8 == 0                     # a tile is whole bytes of the per-window bitmaps
+                assert reads * L <= 3 * 1024 * 4 - 16           # three staged words per thread
+                assert cap >= reads * lpad + k + 8 and cap % 16 == 0 and cap < 40 * 1024
+                # busy lane-windows: at least 5 % more than plain tiles of 8192 window starts
+                assert reads * wins / 8192.0 >= 1.05 * wins / L
+    assert used > 50
+    # the bench's geometry: 150-base reads, k = 31 -> 68 reads of 15 groups: 1020 of 1024 lanes carry 8 k-mers
+    assert lib.btlbf_plan_read_grid(31, 4, 150, 512, out) == 0 and list(out)[:3] == [68, 15, 152]
+    assert lib.btlbf_plan_read_grid(31, 4, 1000, 512, out) == 0 and list(out) == [0, 0, 0, 0]  # long reads: no gain
+    assert lib.btlbf_plan_read_grid(31, 4, 150, 4096, out) != 0  # argument check
