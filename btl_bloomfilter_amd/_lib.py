@@ -94,6 +94,9 @@ _PROTOS = {
     "btlbf_contains_hashes": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, _P]),
     "btlbf_insert_and_check_hashes": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "btlbf_min_count_hashes": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, _P]),
+    "btlbf_insert_kmers": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
+    "btlbf_contains_kmers": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, _P]),
+    "btlbf_hash_kmers": (C.c_int, [C.c_uint, C.c_uint, _P, C.c_uint64, _P, _P, C.c_int, C.c_int, _P]),
     "btlbf_hash_seqs": (C.c_int, [C.c_uint, C.c_uint, C.POINTER(C.c_char_p), C.c_uint, C.c_uint, _P, C.c_uint64,
                                   C.POINTER(Layout), _P, _P, _P, C.c_int, C.c_int, _P]),
     "btlbf_popcount": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

@@ -79,27 +79,28 @@ __device__ __forceinline__ void hash_row_op(int op, void* filter, const ModParam
 	}
 }
 
-// one lane per hash row
+// one lane per hash row; rows whose row_valid byte is 0 are skipped (out = 0)
 template <bool POW2>
 __global__ __launch_bounds__(256) void hash_rows_kernel(int op, void* filter, ModParams mod, uint32_t h,
                                                         uint32_t threshold, const uint64_t* hashes,
-                                                        uint64_t n, uint8_t* out)
+                                                        uint64_t n, const uint8_t* row_valid, uint8_t* out)
 {
 	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n;
 	     r += (uint64_t)gridDim.x * blockDim.x) {
 		uint8_t o = 0;
-		hash_row_op<POW2>(op, filter, mod, h, threshold, hashes + r * h, &o);
+		if (!row_valid || row_valid[r])
+			hash_row_op<POW2>(op, filter, mod, h, threshold, hashes + r * h, &o);
 		if (out)
 			out[r] = o;
 	}
 }
 
 // strict row order on one lane: the only reproducible form of the order-dependent operations
-// (incrementMin, insertAndCheck on streams with repeats)
+// (incrementMin, insertAndCheck on streams with repeats); valid_bits: one bit per row, row_valid: one byte
 template <bool POW2>
 __global__ void hash_rows_serial_kernel(int op, void* filter, ModParams mod, uint32_t h,
                                         uint32_t threshold, const uint64_t* hashes, uint64_t n,
-                                        const uint8_t* valid_bits, uint8_t* out)
+                                        const uint8_t* valid_bits, const uint8_t* row_valid, uint8_t* out)
 {
 	if (blockIdx.x != 0 || threadIdx.x != 0)
 		return;
@@ -107,24 +108,26 @@ __global__ void hash_rows_serial_kernel(int op, void* filter, ModParams mod, uin
 		if (valid_bits && !((valid_bits[r >> 3] >> (r & 7)) & 1))
 			continue;
 		uint8_t o = 0;
-		hash_row_op<POW2>(op, filter, mod, h, threshold, hashes + r * h, &o);
+		if (!row_valid || row_valid[r])
+			hash_row_op<POW2>(op, filter, mod, h, threshold, hashes + r * h, &o);
 		if (out)
 			out[r] = o;
 	}
 }
 
 hipError_t launch_hash_op(int op, void* filter, const ModParams& mod, uint32_t h, uint32_t threshold,
-                          const uint64_t* hashes, uint64_t n, uint8_t* out, int serial, hipStream_t s)
+                          const uint64_t* hashes, uint64_t n, uint8_t* out, int serial, hipStream_t s,
+                          const uint8_t* row_valid)
 {
 	if (n == 0)
 		return hipSuccess;
 	if (serial) {
 		if (mod.pow2)
 			hipLaunchKernelGGL(hash_rows_serial_kernel<true>, dim3(1), dim3(64), 0, s, op, filter, mod, h,
-			                   threshold, hashes, n, (const uint8_t*)nullptr, out);
+			                   threshold, hashes, n, (const uint8_t*)nullptr, row_valid, out);
 		else
 			hipLaunchKernelGGL(hash_rows_serial_kernel<false>, dim3(1), dim3(64), 0, s, op, filter, mod, h,
-			                   threshold, hashes, n, (const uint8_t*)nullptr, out);
+			                   threshold, hashes, n, (const uint8_t*)nullptr, row_valid, out);
 		return hipGetLastError();
 	}
 	uint64_t blocks = (n + 255) / 256;
@@ -132,10 +135,115 @@ hipError_t launch_hash_op(int op, void* filter, const ModParams& mod, uint32_t h
 		blocks = 2048;
 	if (mod.pow2)
 		hipLaunchKernelGGL(hash_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, op, filter, mod,
-		                   h, threshold, hashes, n, out);
+		                   h, threshold, hashes, n, row_valid, out);
 	else
 		hipLaunchKernelGGL(hash_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, op, filter, mod,
-		                   h, threshold, hashes, n, out);
+		                   h, threshold, hashes, n, row_valid, out);
+	return hipGetLastError();
+}
+
+// ---- raw k-mers: KmerBloomFilter::insert / contains(const char*) (KmerBloomFilter.hpp:47-74) -----------
+// The reference hashes a raw k-mer with NTC64(kmerSeq, k) (vendor/nthash.hpp:394-439,460-465): a walk through
+// 4-/3-/2-mer tables indexed by convertTab / RCconvertTab codes -- a Horner chain over base codes, with
+// rolx(h,4) + swapxbits033(h,4) = srol^4.  Its values differ from the iterator's (NTMC64) in the cases below, and
+// this kernel returns what the reference's x86-64 build returns (tests/golden/hash_vectors.json "kmer"):
+//   * U/u read as A (convertTab 0, RCconvertTab 3; nthash.hpp:16-86), except in a one-base remainder
+//     (k % 4 == 1), which goes through seedTab and reads U as T (:416-417,432-433);
+//   * k % 4 == 0: the forward walk ends with rolx(h, 0) and swapxbits033(h, 0); their shifts by 64 execute as
+//     shifts by 0 on x86-64, so h becomes h ^ (y | y << 33) with y = h ^ (h >> 33) (:354-356,388-391,404-406);
+//   * a byte that is not a base has code 255 and table indices / offsets are uint8_t: they wrap modulo 256;
+//   * a 2- or 3-base remainder whose wrapped index lies beyond dimerTab[16] / trimerTab[64] reads outside the
+//     reference's tables (undefined): the k-mer is reported invalid and skipped.
+// One lane per k-mer; rows[r*h ..] = the h hash values (NTE64, :537-542), valid[r] = 0 for a skipped k-mer.
+__device__ __forceinline__ uint32_t kmer_conv(uint32_t c, bool rc)
+{
+	switch (c) {
+	case 'A': case 'a': case 'U': case 'u': return rc ? 3u : 0u;
+	case 'C': case 'c': return rc ? 2u : 1u;
+	case 'G': case 'g': return rc ? 1u : 2u;
+	case 'T': case 't': return rc ? 0u : 3u;
+	default: return 255u;
+	}
+}
+__device__ __forceinline__ uint64_t kmer_seed(uint32_t d)
+{
+	return d == 0 ? kSeedA : d == 1 ? kSeedC : d == 2 ? kSeedG : kSeedT;
+}
+// seedTab (vendor/nthash.hpp:195-228), for the one-base remainder
+__device__ __forceinline__ uint64_t kmer_seed_tab(uint32_t c)
+{
+	switch (c) {
+	case 'A': case 'a': case 4: case 5: return kSeedA;
+	case 'C': case 'c': case 7: return kSeedC;
+	case 'G': case 'g': case 3: return kSeedG;
+	case 'T': case 't': case 'U': case 'u': case 1: return kSeedT;
+	default: return 0;
+	}
+}
+// h <- srol^n(h) ^ table_n[idx]: n Horner steps over the base-4 digits of idx, most significant first
+__device__ __forceinline__ uint64_t kmer_mer_step(uint64_t hv, uint32_t idx, int n)
+{
+	for (int j = n - 1; j >= 0; --j)
+		hv = srol1(hv) ^ kmer_seed((idx >> (2 * j)) & 3u);
+	return hv;
+}
+
+__global__ __launch_bounds__(256) void kmer_rows_kernel(const uint8_t* kmers, uint64_t n, uint32_t k, uint32_t h,
+                                                        uint64_t kms, uint64_t* rows, uint8_t* valid)
+{
+	const uint32_t q = k / 4, r = k % 4;
+	for (uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n;
+	     row += (uint64_t)gridDim.x * blockDim.x) {
+		const uint8_t* s = kmers + row * k;
+		uint64_t f = 0, v = 0;
+		bool ok = true;
+		for (uint32_t i = 0; i < q; ++i) { // NTF64(kmerSeq, k), :394-407
+			const uint32_t off = (4 * i) & 255u;
+			const uint32_t loc = (64 * kmer_conv(s[off], false) + 16 * kmer_conv(s[off + 1], false) +
+			                      4 * kmer_conv(s[off + 2], false) + kmer_conv(s[off + 3], false)) & 255u;
+			f = kmer_mer_step(f, loc, 4);
+		}
+		if (r == 0) {
+			const uint64_t y = f ^ (f >> 33);
+			f ^= y | (y << 33);
+		} else if (r == 1) {
+			f = srol1(f) ^ kmer_seed_tab(s[k - 1]);
+			v = kmer_seed_tab(s[k - 1] & 7u);
+		} else {
+			uint32_t lf = 0, lr = 0;
+			for (uint32_t j = 0; j < r; ++j) {
+				lf = 4 * lf + kmer_conv(s[k - r + j], false);
+				lr = 4 * lr + kmer_conv(s[k - 1 - j], true);
+			}
+			lf &= 255u;
+			lr &= 255u;
+			ok = lf < (1u << (2 * r)) && lr < (1u << (2 * r));
+			f = kmer_mer_step(f, lf, (int)r);
+			v = kmer_mer_step(0, lr, (int)r);
+		}
+		for (uint32_t i = 0; i < q; ++i) { // NTR64(kmerSeq, k), :423-439
+			const uint32_t off = (4 * (q - i) - 1) & 255u;
+			const uint32_t loc = (64 * kmer_conv(s[off], true) + 16 * kmer_conv(s[off - 1], true) +
+			                      4 * kmer_conv(s[off - 2], true) + kmer_conv(s[off - 3], true)) & 255u;
+			v = kmer_mer_step(v, loc, 4);
+		}
+		const uint64_t b = v < f ? v : f; // NTC64, :460-465
+		rows[row * h] = ok ? b : 0;
+		for (uint32_t i = 1; i < h; ++i)
+			rows[row * h + i] = ok ? extra_hash(b, kms, i) : 0;
+		valid[row] = ok ? 1 : 0;
+	}
+}
+
+hipError_t launch_kmer_rows(const uint8_t* kmers, uint64_t n, uint32_t k, uint32_t h, uint64_t kms, uint64_t* rows,
+                            uint8_t* valid, hipStream_t s)
+{
+	if (n == 0)
+		return hipSuccess;
+	uint64_t blocks = (n + 255) / 256;
+	if (blocks > 4096)
+		blocks = 4096;
+	hipLaunchKernelGGL(kmer_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, kmers, n, k, h, kms, rows, valid);
 	return hipGetLastError();
 }
 
@@ -148,10 +256,10 @@ hipError_t launch_serial_seq_update(const SeqArgs& a, int op, const uint64_t* ha
 		return hipSuccess;
 	if (a.mod.pow2)
 		hipLaunchKernelGGL(hash_rows_serial_kernel<true>, dim3(1), dim3(64), 0, s, op, a.filter, a.mod,
-		                   a.hp.h, a.threshold, hashes, a.len, valid_bits, out);
+		                   a.hp.h, a.threshold, hashes, a.len, valid_bits, (const uint8_t*)nullptr, out);
 	else
 		hipLaunchKernelGGL(hash_rows_serial_kernel<false>, dim3(1), dim3(64), 0, s, op, a.filter, a.mod,
-		                   a.hp.h, a.threshold, hashes, a.len, valid_bits, out);
+		                   a.hp.h, a.threshold, hashes, a.len, valid_bits, (const uint8_t*)nullptr, out);
 	return hipGetLastError();
 }
 

@@ -2340,6 +2340,111 @@ extern "C" int btlbf_min_count_hashes(btlbf_filter* f, const uint64_t* hashes, u
 }
 
 // -------------------------------------------------------------------------------------------------
+// raw k-mers: KmerBloomFilter::insert / contains(const char*) (KmerBloomFilter.hpp:47-74)
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+// n k-mers of k bytes each -> device hash rows + valid bytes (aux_kernels.hip, kmer_rows_kernel)
+struct KmerRows {
+	DevBuf seq, rows, valid;
+	const uint8_t* d_seq = nullptr;
+	int prepare(const char* kmers, uint64_t n, unsigned k, unsigned h, uint64_t kms, int mem, hipStream_t s)
+	{
+		if (n && !kmers)
+			return fail(BTLBF_EINVAL, "null kmers");
+		d_seq = reinterpret_cast<const uint8_t*>(kmers);
+		if (mem == BTLBF_HOST) {
+			HIP_TRY(seq.alloc(n * k));
+			if (n)
+				HIP_TRY(hipMemcpyAsync(seq.p, kmers, n * k, hipMemcpyHostToDevice, s));
+			d_seq = seq.as<uint8_t>();
+		}
+		HIP_TRY(rows.alloc(n * h * 8));
+		HIP_TRY(valid.alloc(n));
+		HIP_TRY(launch_kmer_rows(d_seq, n, k, h, kms, rows.as<uint64_t>(), valid.as<uint8_t>(), s));
+		return BTLBF_OK;
+	}
+};
+
+int run_kmer_rows(btlbf_filter* f, int hop, const char* kmers, uint64_t n, uint8_t* out, int serial, int mem,
+                  void* stream)
+{
+	if (f->hp.n_seeds)
+		return fail(BTLBF_EINVAL, "raw k-mers are hashed with ntHash, not with spaced seeds");
+	if (f->shard_count != 1 && hop != H_BF_INSERT)
+		return fail(BTLBF_EINVAL, "only insert is defined on a single shard");
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	MATERIALIZE(f, s);
+	KmerRows kr;
+	int rc = kr.prepare(kmers, n, f->k, f->h, f->hp.kms, mem, s);
+	if (rc)
+		return rc;
+	OutBuf ob;
+	if ((rc = ob.prepare(out, n, mem, false, s)))
+		return rc;
+	HIP_TRY(launch_hash_op(hop, f->d_data, f->mod, f->h, f->thr, kr.rows.as<uint64_t>(), n, static_cast<uint8_t*>(ob.d),
+	                       serial, s, kr.valid.as<uint8_t>()));
+	if ((rc = ob.finish(s)))
+		return rc;
+	HIP_TRY(hipStreamSynchronize(s)); // the temporaries are freed on return
+	return BTLBF_OK;
+}
+
+} // namespace
+
+extern "C" int btlbf_insert_kmers(btlbf_filter* f, const char* kmers, uint64_t n, int op, int order, int mem,
+                                  void* stream)
+{
+	FilterLock lk__(f);
+	if (!f)
+		return fail(BTLBF_EINVAL, "null filter");
+	int hop = H_BF_INSERT;
+	if (f->kind == BTLBF_COUNTING8) {
+		if (op != BTLBF_INCREMENT_MIN && op != BTLBF_INCREMENT_ALL)
+			return fail(BTLBF_EINVAL, "op must be BTLBF_INCREMENT_MIN or BTLBF_INCREMENT_ALL");
+		hop = op == BTLBF_INCREMENT_MIN ? H_CBF_INC_MIN : H_CBF_INC_ALL;
+	}
+	const int serial = f->kind == BTLBF_COUNTING8 && order == BTLBF_ORDER_SERIAL;
+	return run_kmer_rows(f, hop, kmers, n, nullptr, serial, mem, stream);
+}
+
+extern "C" int btlbf_contains_kmers(btlbf_filter* f, const char* kmers, uint64_t n, uint8_t* out, int mem,
+                                    void* stream)
+{
+	FilterLock lk__(f);
+	if (!f || !out)
+		return fail(BTLBF_EINVAL, "null argument");
+	return run_kmer_rows(f, f->kind == BTLBF_BLOOM ? H_BF_CONTAINS : H_CBF_CONTAINS, kmers, n, out, 0, mem, stream);
+}
+
+extern "C" int btlbf_hash_kmers(unsigned kmer_size, unsigned hash_num, const char* kmers, uint64_t n,
+                                uint64_t* hashes, uint8_t* valid, int mem, int device, void* stream)
+{
+	if (kmer_size == 0 || kmer_size > 32768 || hash_num == 0 || hash_num > 64)
+		return fail(BTLBF_EINVAL, "bad kmer_size / hash_num");
+	if (!hashes)
+		return fail(BTLBF_EINVAL, "null hashes output");
+	if (btlbf_device_count() <= device || device < 0)
+		return fail(BTLBF_EHIP, "no GPU %d (visible devices: %d): this library has no CPU path", device,
+		            btlbf_device_count());
+	DeviceGuard g(device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	KmerRows kr;
+	int rc = kr.prepare(kmers, n, kmer_size, hash_num, (uint64_t)kmer_size * kMultiSeed, mem, s);
+	if (rc)
+		return rc;
+	const hipMemcpyKind kind = mem == BTLBF_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+	if (n) {
+		HIP_TRY(hipMemcpyAsync(hashes, kr.rows.p, n * hash_num * 8, kind, s));
+		if (valid)
+			HIP_TRY(hipMemcpyAsync(valid, kr.valid.p, n, kind, s));
+	}
+	HIP_TRY(hipStreamSynchronize(s));
+	return BTLBF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
 // hash streams only
 // -------------------------------------------------------------------------------------------------
 extern "C" int btlbf_hash_seqs(unsigned kmer_size, unsigned hash_num, const char* const* seeds,

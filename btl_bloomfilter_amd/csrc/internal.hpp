@@ -207,7 +207,11 @@ hipError_t launch_spill(void* filter, const uint64_t* pos, uint64_t n, uint64_t 
                         const PartSide& sd, hipStream_t s);
 hipError_t launch_seq_op(int op, const SeqArgs& a, hipStream_t s);
 hipError_t launch_hash_op(int op, void* filter, const ModParams& mod, uint32_t h, uint32_t threshold,
-                          const uint64_t* hashes, uint64_t n, uint8_t* out, int serial, hipStream_t s);
+                          const uint64_t* hashes, uint64_t n, uint8_t* out, int serial, hipStream_t s,
+                          const uint8_t* row_valid = nullptr);
+// raw k-mers (KmerBloomFilter's NTC64(kmerSeq, k) path) -> hash rows + one valid byte per k-mer
+hipError_t launch_kmer_rows(const uint8_t* kmers, uint64_t n, uint32_t k, uint32_t h, uint64_t kms, uint64_t* rows,
+                            uint8_t* valid, hipStream_t s);
 hipError_t launch_serial_seq_update(const SeqArgs& a, int op, const uint64_t* hashes,
                                     const uint8_t* valid_bits, uint8_t* out, hipStream_t s);
 hipError_t launch_popcount(const void* data, uint64_t nbytes, int mode, uint32_t threshold,

@@ -337,31 +337,74 @@ class KmerBloomFilter(BloomFilter):
     """The surface the reference's SWIG module exposes as `BloomFilter` (swig/BloomFilter.i:17-59 =
     KmerBloomFilter.hpp:17-75): insert / contains take either a k-mer string or a row of precomputed
     hashes; together with insertSeq() below this replaces both the SWIG/Perl binding and the stale
-    Boost.Python module under pythonInterface/.  K-mer strings are hashed on the GPU like a one-window
-    sequence (always the iterator's hash; see include/btlbf/KmerBloomFilter.hpp for the two corner
-    cases of the reference's tetramer path that are not reproduced)."""
+    Boost.Python module under pythonInterface/.  K-mer strings are hashed on the GPU with the values of the
+    reference's raw-k-mer path, NTC64(kmerSeq, k) -- which are not the iterator's for k % 4 == 0 and for
+    k-mers with U (btlbf_insert_kmers in include/btlbf.h has the details)."""
 
     @staticmethod
     def _is_kmer(x):
         return isinstance(x, (str, bytes, bytearray))
 
-    def _kmer(self, x):
-        b = x.encode() if isinstance(x, str) else bytes(x)
-        if len(b) < self.getKmerSize():
-            raise ValueError("k-mer shorter than kmerSize")
-        return np.frombuffer(b[: self.getKmerSize()], np.uint8)
+    def _kmers(self, x):
+        """one k-mer string, or a list of them -> (uint8 buffer of n*k bytes, n)"""
+        k = self.getKmerSize()
+        items = [x] if self._is_kmer(x) else list(x)
+        out = bytearray()
+        for it in items:
+            b = it.encode("latin-1") if isinstance(it, str) else bytes(it)
+            if len(b) < k:
+                raise ValueError("k-mer shorter than kmerSize")
+            out += b[:k]
+        return np.frombuffer(bytes(out), np.uint8), len(items)
+
+    def insertKmers(self, kmers, stream=None):
+        """KmerBloomFilter::insert(const char*) for a batch of raw k-mers (strings, or a uint8 buffer of n*k)"""
+        buf, n = self._kmers(kmers) if not isinstance(kmers, np.ndarray) and not _is_torch_cuda(kmers) else (
+            kmers, None)
+        b = _Buf(buf)
+        n = b.nbytes // self.getKmerSize() if n is None else n
+        check(self._L.btlbf_insert_kmers(self._h, b.ptr, n, 0, ORDER_PARALLEL, b.mem, _stream_ptr(stream, b.keep)))
+
+    def containsKmers(self, kmers, stream=None):
+        """KmerBloomFilter::contains(const char*) for a batch of raw k-mers -> uint8 array"""
+        buf, n = self._kmers(kmers) if not isinstance(kmers, np.ndarray) and not _is_torch_cuda(kmers) else (
+            kmers, None)
+        b = _Buf(buf)
+        n = b.nbytes // self.getKmerSize() if n is None else n
+        if b.mem == DEVICE:
+            import torch
+
+            out = torch.zeros(n, dtype=torch.uint8, device=b.keep.device)
+            optr = C.c_void_p(out.data_ptr())
+        else:
+            out = np.zeros(max(n, 1), np.uint8)
+            optr = C.c_void_p(out.ctypes.data)
+        check(self._L.btlbf_contains_kmers(self._h, b.ptr, n, optr, b.mem, _stream_ptr(stream, b.keep)))
+        return out[:n]
 
     def insert(self, x, stream=None):
         if self._is_kmer(x):
-            return self.insertSeqs(self._kmer(x), stream=stream)
+            return self.insertKmers(x, stream=stream)
         return super().insert(x, stream=stream)
 
     def contains(self, x, stream=None):
         if self._is_kmer(x):
-            hit, _ = self.containsSeqs(self._kmer(x), want_valid=False, stream=stream)[:2]
-            return bool(int(np.asarray(hit).view(np.uint64)[0]) & 1)
+            return bool(self.containsKmers(x, stream=stream)[0])
         r = super().contains(x, stream=stream)
         return bool(r[0]) if np.ndim(x) == 1 else r
+
+
+def hash_kmers(kmers, h, k, device=0):
+    """NTC64(kmerSeq, k) + NTE64 of raw k-mers (KmerBloomFilter's path; bytes of n*k) -> (hashes[n, h], valid[n])"""
+    b = _Buf(kmers)
+    n = b.nbytes // k
+    hv = np.zeros((max(n, 1), h), np.uint64)
+    ok = np.zeros(max(n, 1), np.uint8)
+    if b.mem != HOST:
+        raise ValueError("hash_kmers takes host buffers")
+    check(_lib.load().btlbf_hash_kmers(k, h, b.ptr, n, C.c_void_p(hv.ctypes.data), C.c_void_p(ok.ctypes.data), HOST,
+                                       device, None))
+    return hv[:n], ok[:n]
 
 
 def insertSeq(bloom, seq, numHashes=None, k=None):

@@ -220,6 +220,22 @@ int btlbf_insert_and_check_hashes(btlbf_filter* f, const uint64_t* hashes, uint6
 int btlbf_min_count_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n, uint8_t* min_out,
                            int mem, void* stream);
 
+/* ---- raw k-mers: KmerBloomFilter::insert(const char*) / contains(const char*) --------------------
+ * (KmerBloomFilter.hpp:47-74 -> NTC64(kmerSeq, k) vendor/nthash.hpp:394-439,460-465 + NTE64 :537-542)
+ * `kmers` = n k-mers of kmer_size bytes each, back to back.  The values are the ones the reference's
+ * x86-64 build returns on this path, which differ from the iterator's (NTMC64) for k % 4 == 0 (the table
+ * walk's shift by 64, :354-356,388-391,404-406) and for k-mers with U/u (read as A, :16-86, except in a
+ * one-base remainder).  Bytes that are not ACGTU/acgtu wrap the reference's uint8_t table index to some
+ * other 4-mer, as there; a k-mer whose 2-/3-base remainder then indexes beyond the reference's tables has
+ * no defined value and is skipped (insert: nothing, contains: 0, valid: 0).
+ * op / order as btlbf_insert_hashes (counting filters); out[i] = contains() of k-mer i. */
+int btlbf_insert_kmers(btlbf_filter* f, const char* kmers, uint64_t n, int op, int order, int mem,
+                       void* stream);
+int btlbf_contains_kmers(btlbf_filter* f, const char* kmers, uint64_t n, uint8_t* out, int mem, void* stream);
+/* the hash values alone: hashes[i*hash_num ..) and (optionally) valid[i] for k-mer i */
+int btlbf_hash_kmers(unsigned kmer_size, unsigned hash_num, const char* kmers, uint64_t n, uint64_t* hashes,
+                     uint8_t* valid, int mem, int device, void* stream);
+
 /* ---- hash streams only (iterator parity) -------------------------------------------------------
  * ntHashIterator (vendor/ntHashIterator.hpp:38,93): hashes[p*h .. p*h+h) for window p (zeros when
  * not clean), valid_bits as above.  With seeds != NULL: stHashIterator(seq, seeds, n_seeds, h2, k)

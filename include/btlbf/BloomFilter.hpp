@@ -3,9 +3,11 @@
 //
 // Same class name, constructors and method names as the reference; every call forwards to the C
 // ABI (include/btlbf.h), i.e. to the HIP kernels -- nothing is computed on the host.
-//   * insert(hashes) is write-combined: rows are queued on the host and pushed to the GPU in one
-//     btlbf_insert_hashes call when the queue fills or before anything reads the filter.  Bit OR is
-//     order-free, so this is invisible to callers (reference: BloomFilter.hpp:171-194).
+//   * inserts are write-combined: hash rows (insert(hashes)), whole sequences (insertSeq) and raw k-mers
+//     (KmerBloomFilter::insert(const char*)) are queued on the host and pushed to the GPU in one batch call
+//     (btlbf_insert_hashes / one ragged btlbf_insert_seqs / btlbf_insert_kmers) when a queue fills or before
+//     anything reads the filter.  Bit OR is order-free, so this is invisible to callers (reference:
+//     BloomFilter.hpp:171-194, BloomFilterUtil.h:9-17).
 //   * threads: as in the reference, insert / insertAndCheck / contains may be called on ONE filter from
 //     many threads at once (Tests/AdHoc/ParallelFilter.cpp:104-122 does so under OpenMP; the reference
 //     relies on byte atomics, BloomFilter.hpp:177,191,206-210).  Here the queue is striped -- a thread
@@ -69,7 +71,7 @@ class BloomFilter
 		btlbf_destroy(m_f);
 		m_f = nullptr;
 		for (auto& st : m_stripes)
-			st.rows.clear();
+			st.clear();
 		btlbf_shim::check(
 		    btlbf_load(&m_f, BTLBF_BLOOM, filterFilePath.c_str(), 0, btlbf_shim::default_device()));
 	}
@@ -94,7 +96,7 @@ class BloomFilter
 		btlbf_destroy(m_f);
 		m_f = nullptr;
 		for (auto& st : m_stripes)
-			st.rows.clear();
+			st.clear();
 		btlbf_shim::check(btlbf_create_from_header(&m_f, BTLBF_BLOOM, text.data(), text.size(), 0,
 		                                           btlbf_shim::default_device()));
 	}
@@ -118,7 +120,7 @@ class BloomFilter
 	void insert(const uint64_t precomputed[]) // BloomFilter.hpp:185-194
 	{
 		const unsigned h = getHashNum();
-		Stripe& st = m_stripes[std::hash<std::thread::id>()(std::this_thread::get_id()) % kStripes];
+		Stripe& st = my_stripe();
 		std::lock_guard<std::mutex> g(st.mu);
 		st.rows.insert(st.rows.end(), precomputed, precomputed + h);
 		// pushed under the stripe's lock: a flush() (= any reader) that finds the stripe empty must be able to
@@ -176,12 +178,29 @@ class BloomFilter
 		out.resize(n);
 		return out;
 	}
-	// every k-mer of `seq` (ntHashIterator semantics: windows with non-ACGT bytes are skipped)
-	void insertSeq(const std::string& seq)
+	// every k-mer of `seq` (ntHashIterator semantics: windows with non-ACGT bytes are skipped): the loop of
+	// BloomFilterUtil.h:9-17.  Queued like insert(hashes): sequences are appended to the calling thread's stripe
+	// and reach the GPU as ONE ragged btlbf_insert_seqs batch (offsets in starts[]), not one launch each.
+	void insertSeq(const std::string& seq) { insertSeq(seq.data(), seq.size()); }
+	void insertSeq(const char* seq, size_t len)
 	{
-		flush();
-		btlbf_shim::check(btlbf_insert_seqs(m_f, seq.data(), seq.size(), nullptr, 0, BTLBF_ORDER_PARALLEL,
-		                                    BTLBF_HOST, nullptr));
+		if (len < getKmerSize())
+			return; // no k-mer (ntHashIterator.hpp:61-64)
+		Stripe& st = my_stripe();
+		std::lock_guard<std::mutex> g(st.mu);
+		st.starts.push_back(st.seqs.size());
+		st.seqs.append(seq, len);
+		if (st.seqs.size() >= kFlushBases) {
+			push_seqs(st);
+			st.seqs.clear();
+			st.starts.clear();
+		}
+	}
+	// many sequences in one call (a batch of reads): result as if insertSeq were called on each
+	void insertSeqs(const std::vector<std::string>& seqs)
+	{
+		for (const auto& s : seqs)
+			insertSeq(s);
 	}
 	// every k-mer of a FASTA / FASTQ / one-sequence-per-line file, gzip or plain (the job of the
 	// reference's loaders Tests/AdHoc/ParallelFilter.cpp:104-122 and swig/writeBloom_rolling.cpp:18-59);
@@ -299,29 +318,63 @@ class BloomFilter
 	BloomFilter(const BloomFilter&) = delete; // BloomFilter.hpp:384
 	BloomFilter& operator=(const BloomFilter&) = delete;
 
+	struct Stripe {
+		std::mutex mu;
+		std::vector<uint64_t> rows;   // hash rows, m_hashNum each
+		std::string seqs;             // whole sequences, back to back ...
+		std::vector<uint64_t> starts; // ... and where each begins (btlbf_layout::starts without its end sentinel)
+		std::string kmers;            // raw k-mers, m_kmerSize bytes each (KmerBloomFilter)
+		void clear()
+		{
+			rows.clear();
+			seqs.clear();
+			starts.clear();
+			kmers.clear();
+		}
+	};
+	Stripe& my_stripe() const
+	{
+		return m_stripes[std::hash<std::thread::id>()(std::this_thread::get_id()) % kStripes];
+	}
 	void push(const std::vector<uint64_t>& rows) const
 	{
 		btlbf_shim::check(btlbf_insert_hashes(m_f, rows.data(), rows.size() / getHashNum(), 0, BTLBF_ORDER_PARALLEL,
 		                                      BTLBF_HOST, nullptr));
+	}
+	void push_seqs(Stripe& st) const
+	{
+		st.starts.push_back(st.seqs.size()); // end sentinel
+		btlbf_layout lay;
+		lay.starts = st.starts.data();
+		lay.n_seqs = st.starts.size() - 1;
+		lay.read_len = 0;
+		btlbf_shim::check(btlbf_insert_seqs(m_f, st.seqs.data(), st.seqs.size(), &lay, 0, BTLBF_ORDER_PARALLEL,
+		                                    BTLBF_HOST, nullptr));
+	}
+	void push_kmers(const std::string& kmers) const
+	{
+		btlbf_shim::check(btlbf_insert_kmers(m_f, kmers.data(), kmers.size() / getKmerSize(), 0, BTLBF_ORDER_PARALLEL,
+		                                     BTLBF_HOST, nullptr));
 	}
 	// everything queued by any thread so far reaches the filter
 	void flush() const
 	{
 		for (auto& st : m_stripes) {
 			std::lock_guard<std::mutex> g(st.mu);
-			if (!st.rows.empty()) {
+			if (!st.rows.empty())
 				push(st.rows);
-				st.rows.clear();
-			}
+			if (!st.seqs.empty())
+				push_seqs(st);
+			if (!st.kmers.empty())
+				push_kmers(st.kmers);
+			st.clear();
 		}
 	}
 
 	static constexpr size_t kFlushRows = 1u << 16;
+	static constexpr size_t kFlushBases = 32u << 20; // bases queued per stripe before a push
+	static constexpr size_t kFlushKmers = 1u << 16;
 	static constexpr size_t kStripes = 16;
-	struct Stripe {
-		std::mutex mu;
-		std::vector<uint64_t> rows;
-	};
 	btlbf_filter* m_f = nullptr;
 	mutable Stripe m_stripes[kStripes];
 	double m_FPR = 0;

@@ -129,6 +129,127 @@ bo_multi(uint64_t b, unsigned k, unsigned h, uint64_t* hv)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Raw k-mer hashes: NTF64 / NTR64 / NTC64 (kmerSeq, k) of nthash.hpp:394-439,460-465 -- what
+ * KmerBloomFilter::insert/contains(const char*) hash with (KmerBloomFilter.hpp:47-74).
+ *
+ * The reference walks the k-mer through 4-, 3- and 2-mer tables indexed by convertTab /
+ * RCconvertTab codes.  tetramerTab[64a+16b+4c+d] = srol^3(s[a]) ^ srol^2(s[b]) ^ srol(s[c]) ^ s[d]
+ * (s = the four seeds; likewise trimerTab, dimerTab), and rolx(h,4) + swapxbits033(h,4) = srol^4,
+ * so the walk is a Horner chain over base codes.  What differs from the iterator path, restated
+ * here as the reference BEHAVES when built with g++ for x86-64 (the build the goldens come from):
+ *   - convertTab sends U/u to A and RCconvertTab sends it to T's code, i.e. U reads as A
+ *     (nthash.hpp:16-86) -- except in a one-base remainder (k % 4 == 1), which goes through
+ *     seedTab and reads U as T (:416-417,432-433);
+ *   - k % 4 == 0: the forward walk ends with rolx(h, 0) and swapxbits033(h, 0), whose shifts by
+ *     64 execute as shifts by 0 on x86-64: rolx returns h, swapxbits033 returns
+ *     h ^ (y | y << 33) with y = h ^ (h >> 33) (:354-356,388-391,404-406); NTR64 has no such step;
+ *   - a byte that is not a base has code 255 and the table index is a uint8_t: the index wraps
+ *     modulo 256 to some other 4-mer; the offsets into the k-mer are uint8_t too (:401,430) and
+ *     wrap for k > 256;
+ *   - a remainder of 2 or 3 bases whose wrapped index falls outside dimerTab[16] / trimerTab[64]
+ *     reads beyond the table: undefined, no value to restate -> returns 0 (k-mer skipped).
+ * ---------------------------------------------------------------------------------------- */
+static unsigned
+conv_code(unsigned char c) /* convertTab, nthash.hpp:50-83 */
+{
+	switch (c) {
+	case 'A': case 'a': case 'U': case 'u': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': return 3;
+	default: return 255;
+	}
+}
+static unsigned
+rc_code(unsigned char c) /* RCconvertTab, nthash.hpp:16-49 */
+{
+	switch (c) {
+	case 'A': case 'a': case 'U': case 'u': return 3;
+	case 'C': case 'c': return 2;
+	case 'G': case 'g': return 1;
+	case 'T': case 't': return 0;
+	default: return 255;
+	}
+}
+static const uint64_t kmer_seed[4] = {SEED_A, SEED_C, SEED_G, SEED_T};
+/* h <- srol^n(h) ^ table_n[idx]: n Horner steps over the base-4 digits of idx, most significant first */
+static uint64_t
+mer_step(uint64_t h, unsigned idx, unsigned n)
+{
+	for (unsigned j = n; j-- > 0;)
+		h = bo_srol(h) ^ kmer_seed[(idx >> (2 * j)) & 3];
+	return h;
+}
+
+int
+bo_kmer_base_hash(const char* kmer, unsigned k, uint64_t* fh, uint64_t* rh)
+{
+	const unsigned char* s = (const unsigned char*)kmer;
+	const unsigned q = k / 4, r = k % 4;
+	uint64_t f = 0, v = 0;
+	/* NTF64(kmerSeq, k), nthash.hpp:394-420 */
+	for (unsigned i = 0; i < q; ++i) {
+		const unsigned off = (4 * i) & 255u; /* uint8_t currOffSet */
+		const unsigned loc = (64 * conv_code(s[off]) + 16 * conv_code(s[off + 1]) + 4 * conv_code(s[off + 2]) +
+		                      conv_code(s[off + 3])) & 255u;
+		f = mer_step(f, loc, 4);
+	}
+	if (r == 0) {
+		const uint64_t y = f ^ (f >> 33);
+		f ^= y | (y << 33);
+	} else if (r == 3) {
+		const unsigned loc = (16 * conv_code(s[k - 3]) + 4 * conv_code(s[k - 2]) + conv_code(s[k - 1])) & 255u;
+		if (loc >= 64)
+			return 0;
+		f = mer_step(f, loc, 3);
+	} else if (r == 2) {
+		const unsigned loc = (4 * conv_code(s[k - 2]) + conv_code(s[k - 1])) & 255u;
+		if (loc >= 16)
+			return 0;
+		f = mer_step(f, loc, 2);
+	} else {
+		f = bo_srol(f) ^ bo_seed(s[k - 1]);
+	}
+	/* NTR64(kmerSeq, k), nthash.hpp:423-439 */
+	if (r == 3) {
+		const unsigned loc = (16 * rc_code(s[k - 1]) + 4 * rc_code(s[k - 2]) + rc_code(s[k - 3])) & 255u;
+		if (loc >= 64)
+			return 0;
+		v = mer_step(0, loc, 3);
+	} else if (r == 2) {
+		const unsigned loc = (4 * rc_code(s[k - 1]) + rc_code(s[k - 2])) & 255u;
+		if (loc >= 16)
+			return 0;
+		v = mer_step(0, loc, 2);
+	} else if (r == 1) {
+		v = bo_seed(s[k - 1] & 7);
+	}
+	for (unsigned i = 0; i < q; ++i) {
+		const unsigned off = (4 * (q - i) - 1) & 255u; /* uint8_t currOffSet */
+		const unsigned loc = (64 * rc_code(s[off]) + 16 * rc_code(s[off - 1]) + 4 * rc_code(s[off - 2]) +
+		                      rc_code(s[off - 3])) & 255u;
+		v = mer_step(v, loc, 4);
+	}
+	*fh = f;
+	*rh = v;
+	return 1;
+}
+
+/* NTC64(kmerSeq, k) + NTE64 (nthash.hpp:460-465,537-542) for n k-mers laid back to back */
+void
+bo_kmer_hashes(const char* kmers, size_t n, unsigned k, unsigned h, uint64_t* hash_out, uint8_t* valid_out)
+{
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t fh, rh;
+		valid_out[i] = (uint8_t)bo_kmer_base_hash(kmers + i * k, k, &fh, &rh);
+		if (valid_out[i])
+			bo_multi(rh < fh ? rh : fh, k, h, hash_out + i * h);
+		else
+			memset(hash_out + i * h, 0, h * sizeof(uint64_t));
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
  * Iterators
  * ---------------------------------------------------------------------------------------- */
 

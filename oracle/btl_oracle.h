@@ -40,6 +40,12 @@ int bo_base_hash(const char* kmer, unsigned k, uint64_t* fh, uint64_t* rh, unsig
 void bo_roll(uint64_t* fh, uint64_t* rh, unsigned k, unsigned char out, unsigned char in); /* :442-457 */
 void bo_multi(uint64_t b, unsigned k, unsigned h, uint64_t* hv); /* :585-589 */
 uint64_t bo_extra(uint64_t b, unsigned k, unsigned i);            /* NTE64 :537-542 */
+/* raw k-mer path of KmerBloomFilter: NTF64/NTR64(kmerSeq,k) as the x86-64 reference build behaves
+ * (:394-439; U read as A, the shift-by-64 step for k % 4 == 0, uint8_t index wrap); returns 0 where the
+ * reference reads beyond its 2-/3-mer tables */
+int bo_kmer_base_hash(const char* kmer, unsigned k, uint64_t* fh, uint64_t* rh);
+/* NTC64(kmerSeq,k) + NTE64 for n k-mers of k bytes each, back to back (:460-465,537-542) */
+void bo_kmer_hashes(const char* kmers, size_t n, unsigned k, unsigned h, uint64_t* hash_out, uint8_t* valid_out);
 
 /* ---- iterators: emit (pos, hashes) for every clean window, in order ---- */
 size_t bo_nthash_seq(const char* seq, size_t len, unsigned h, unsigned k,

@@ -60,6 +60,7 @@ class Oracle:
         L.bo_sthash_seq.restype = C.c_size_t
         L.bo_sthash_seq.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_uint, C.c_uint,
                                     C.c_uint, u64p, u64p, u8p, C.c_size_t]
+        L.bo_kmer_hashes.argtypes = [C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, u64p, u8p]
         L.bo_bf_insert.argtypes = [u8p, C.c_uint64, C.c_uint, u64p, C.c_size_t]
         L.bo_bf_contains.argtypes = [u8p, C.c_uint64, C.c_uint, u64p, C.c_size_t, u8p]
         L.bo_bf_insert_and_check.argtypes = [u8p, C.c_uint64, C.c_uint, u64p, C.c_size_t, u8p]
@@ -108,6 +109,15 @@ class Oracle:
         st = np.zeros(cap * m, np.uint8)
         n = self.L.bo_sthash_seq(s, len(s), arr, len(seeds), h2, k, pos, hv, st, cap)
         return pos[:n].copy(), hv[: n * m].reshape(n, m).copy(), st[: n * m].reshape(n, m).copy()
+
+    def kmer_hashes(self, kmers, k, h):
+        """raw k-mers (bytes, n*k long) -> (hashes [n, h], valid [n]): the KmerBloomFilter path"""
+        s = _bytes(kmers)
+        n = len(s) // k
+        hv = np.zeros(max(n, 1) * h, np.uint64)
+        ok = np.zeros(max(n, 1), np.uint8)
+        self.L.bo_kmer_hashes(s, n, k, h, hv, ok)
+        return hv[: n * h].reshape(n, h).copy(), ok[:n].copy()
 
     # -- bit filter ----------------------------------------------------------------------
     def bf_insert(self, filt, size_bits, h, hashes):

@@ -383,6 +383,75 @@ static void parallel_filter_replay(const char* out_path)
 	}
 }
 
+// swig/test.pl:8-46 in C++: the SWIG module's BloomFilter is KmerBloomFilter (swig/BloomFilter.i:17-59).  k = 20, so
+// insert(const char*) / contains(const char*) go through the reference's k % 4 == 0 table walk; the stored file is
+// compared with the reference's by the Python wrapper (tests/golden/kmer_path.json: file_sha256).
+static void swig_test_pl_replay(const char* out_path)
+{
+	KmerBloomFilter filter(1000000000, 5, 20);
+	filter.insert("ATCGGGTCATCAACCAATAT");
+	filter.insert("ATCGGGTCATCAACCAATAC");
+	filter.insert("ATCGGGTCATCAACCAATAG");
+	filter.insert("ATCGGGTCATCAACCAATAA");
+	CHECK(filter.contains("ATCGGGTCATCAACCAATAT") && filter.contains("ATCGGGTCATCAACCAATAC") &&
+	      filter.contains("ATCGGGTCATCAACCAATAG") && filter.contains("ATCGGGTCATCAACCAATAA"));
+	CHECK(!filter.contains("ATCGGGTCATCAACCAATTA") && !filter.contains("ATCGGGTCATCAACCAATTC"));
+	CHECK(filter.getPop() == 20);
+	const std::string fn = out_path ? std::string(out_path) : tmp_name("swig");
+	filter.storeFilter(fn);
+	KmerBloomFilter filter2(fn);
+	CHECK(filter2.contains("ATCGGGTCATCAACCAATAT") && filter2.contains("ATCGGGTCATCAACCAATAA"));
+	CHECK(!filter2.contains("ATCGGGTCATCAACCAATTA"));
+	CHECK(filter2.getPop() == 20 && filter2.getHashNum() == 5 && filter2.getKmerSize() == 20 &&
+	      filter2.getFilterSize() == 1000000000);
+	const std::vector<uint8_t> r = filter2.containsKmers("ATCGGGTCATCAACCAATATATCGGGTCATCAACCAATTA", 2);
+	CHECK(r.size() == 2 && r[0] == 1 && r[1] == 0);
+	if (!out_path)
+		std::remove(fn.c_str());
+	// swig/test.pl:59-84
+	const std::string str = "TAGAATCACCCAAAGA";
+	KmerBloomFilter bloom(10000, 4, 5);
+	insertSeq(bloom, str, 4, 5);
+	for (size_t i = 0; i + 5 <= str.size(); ++i)
+		CHECK(bloom.contains(str.substr(i, 5).c_str()));
+}
+
+// insertSeq is queued (include/btlbf/BloomFilter.hpp): many short sequences from many threads reach the GPU as a
+// few ragged batches and give the filter the per-sequence loop gives (BloomFilterUtil.h:9-17)
+static void insert_seq_is_write_combined()
+{
+	const unsigned n_reads = 5000, L = 100, h = 3, k = 25;
+	BloomFilter queued(1 << 22, h, k), loop(1 << 22, h, k);
+#pragma omp parallel for
+	for (int r = 0; r < (int)n_reads; ++r) {
+		std::string s = synth_read(9, (uint64_t)r, L);
+		if (r % 7 == 0)
+			s[r % L] = 'N';
+		if (r % 11 == 0)
+			s = s.substr(0, r % 30); // shorter than k now and then, also empty
+		insertSeq(queued, s, h, k);
+	}
+	for (unsigned r = 0; r < n_reads; ++r) {
+		std::string s = synth_read(9, r, L);
+		if (r % 7 == 0)
+			s[r % L] = 'N';
+		if (r % 11 == 0)
+			s = s.substr(0, r % 30);
+		ntHashIterator itr(s, h, k);
+		while (itr != itr.end()) {
+			loop.insert(*itr);
+			++itr;
+		}
+	}
+	CHECK(queued.getPop() == loop.getPop() && queued.getPop() > 0);
+	const std::string fa = tmp_name("q"), fb = tmp_name("l");
+	queued.storeFilter(fa);
+	loop.storeFilter(fb);
+	CHECK(slurp(fa) == slurp(fb));
+	std::remove(fa.c_str());
+	std::remove(fb.c_str());
+}
+
 int main(int argc, char** argv)
 {
 	bloom_basic();
@@ -392,6 +461,8 @@ int main(int argc, char** argv)
 	file_loaders_equal_insert_seq();
 	sizing_ctor_and_load_header();
 	parallel_filter_replay(argc > 2 ? argv[2] : nullptr);
+	swig_test_pl_replay(argc > 3 ? argv[3] : nullptr);
+	insert_seq_is_write_combined();
 	if (g_fail) {
 		std::fprintf(stderr, "%d checks failed\n", g_fail);
 		return 1;

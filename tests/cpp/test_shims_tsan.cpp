@@ -6,6 +6,7 @@
 #define BTLBF_SHIM_MINIMAL
 #include "btlbf/BloomFilter.hpp"
 #include "btlbf/CountingBloomFilter.hpp"
+#include "btlbf/KmerBloomFilter.hpp"
 
 #include <cstdio>
 #include <thread>
@@ -21,7 +22,7 @@ static uint64_t mix(uint64_t z)
 int main()
 {
 	const unsigned h = 4, T = 8, per = 80000;  // > kFlushRows rows per stripe: queues fill and flush under load
-	BloomFilter bloom(1 << 26, h, 31);
+	KmerBloomFilter bloom(1 << 26, h, 31);
 	CountingBloomFilter<uint8_t> cbf(1 << 20, h, 31, 1);
 	std::vector<std::thread> th;
 	std::vector<unsigned long> miss(T, 0);
@@ -36,6 +37,11 @@ int main()
 					miss[t] += !bloom.contains(row);
 					(void)bloom.insertAndCheck(row);
 					(void)bloom.getPop();
+				}
+				if (i % 16 == 0) { // the sequence and raw-k-mer queues, filled and flushed from all threads
+					const std::string seq(40 + i % 300, "ACGT"[i & 3]);
+					bloom.insertSeq(seq);
+					bloom.insert(seq.c_str());
 				}
 				if (i % 64 == 0) {
 					cbf.incrementAll(row);

@@ -243,5 +243,84 @@ def main():
     print("golden fixtures written to", HERE)
 
 
+def kmer_path():
+    """kmer_path.json: the raw-k-mer path KmerBloomFilter::insert/contains(const char*) takes
+    (KmerBloomFilter.hpp:47-74 -> NTC64(kmerSeq, k), nthash.hpp:394-439,460-465), beyond the cases in
+    hash_vectors.json: every k from 1 to 40 and a few large ones (uint8_t offsets wrap above 256), U, bytes that
+    are not bases (the uint8_t table index wraps), and the replay of swig/test.pl.  `defined` = 0 marks k-mers
+    whose 2-/3-base remainder makes the reference index beyond dimerTab / trimerTab (no value to pin)."""
+    ref = Ref()
+    rng = np.random.RandomState(424242)
+    alpha = "ACGT" * 6 + "acgt" * 2 + "UuNn-*" + "\x01\x03\x04\x05\x07"
+    conv = {c: v for v, cs in enumerate(("AaUu", "Cc", "Gg", "Tt")) for c in cs}
+
+    def defined(km, k):
+        r = k % 4
+        if r in (0, 1):
+            return 1
+        idx = 0
+        for c in km[k - r:]:
+            idx = 4 * idx + conv.get(c, 255)
+        ridx = 0
+        for c in reversed(km[k - r:]):
+            ridx = 4 * ridx + (3 - conv[c] if c in conv else 255)
+        return int((idx & 255) < 4 ** r and (ridx & 255) < 4 ** r)
+
+    cases = []
+    for k in list(range(1, 41)) + [64, 100, 255, 256, 257, 260, 300]:
+        for t in range(4):
+            if t == 0:
+                km = rand_seq(rng, k)
+            elif t == 1:
+                km = rand_seq(rng, k, "ACGTacgtUu")
+            else:
+                km = rand_seq(rng, k, alpha)
+            d = defined(km, k)
+            cases.append(dict(kmer=km, k=k, h=3, defined=d,
+                              hashes=hx(ref.kmer_hashes(km.encode("latin-1"), k, 3)) if d else []))
+    out = dict(hashes=cases)
+
+    # swig/test.pl:8-26: BloomFilter(1000000000, 5, 20) = KmerBloomFilter, four raw k-mers inserted, six queried
+    ins = ["ATCGGGTCATCAACCAATAT", "ATCGGGTCATCAACCAATAC", "ATCGGGTCATCAACCAATAG", "ATCGGGTCATCAACCAATAA"]
+    qry = ins + ["ATCGGGTCATCAACCAATTA", "ATCGGGTCATCAACCAATTC"]
+    f = ref.bf(1000000000, 5, 20)
+    for km in ins:
+        f.insert_kmer(km)
+    path = os.path.join(HERE, "_swig_test_pl.bf")
+    f.store(path)
+    raw = open(path, "rb").read()
+    os.remove(path)  # 125 MB: pinned by digest, header and set bits instead
+    hend = raw.index(b"[HeaderEnd]\n") + len(b"[HeaderEnd]\n")
+    body = np.frombuffer(raw, np.uint8, offset=hend)
+    nz = np.flatnonzero(body)
+    setbits = sorted(int(8 * i + b) for i in nz for b in range(8) if (body[i] >> b) & 1)
+    # the same four k-mers through the ITERATOR path land elsewhere (k = 20: k % 4 == 0)
+    g = ref.bf(1000000000, 5, 20)
+    for km in ins:
+        g.insert_seq(km)
+    gb = g.bytes()
+    out["swig_test_pl"] = dict(bits=1000000000, h=5, k=20, inserted=ins, queried=qry,
+                               contains=[int(f.contains_kmer(km)) for km in qry],
+                               header=raw[:hend].decode(), file_sha256=sha(raw), body_sha256=sha(body), pop=f.pop(),
+                               set_bits=setbits, same_as_iterator_path=bool((gb == body).all()))
+    f.close()
+    g.close()
+    # swig/test.pl:59-84: insertSeq + contains(kmer) of every 5-mer
+    s = "TAGAATCACCCAAAGA"
+    f = ref.bf(10000, 4, 5)
+    f.insert_seq(s)
+    out["swig_insert_seq"] = dict(bits=10000, h=4, k=5, seq=s,
+                                  contains=[int(f.contains_kmer(s[i:i + 5])) for i in range(len(s) - 4)],
+                                  body_sha256=sha(f.bytes()))
+    f.close()
+    json.dump(out, open(os.path.join(HERE, "kmer_path.json"), "w"))
+    print("kmer_path.json:", len(cases), "hash cases,", sum(c["defined"] for c in cases), "defined; test.pl pop",
+          out["swig_test_pl"]["pop"], "same as iterator path:", out["swig_test_pl"]["same_as_iterator_path"])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "kmer":
+        kmer_path()  # only kmer_path.json (added in round 3; the other fixtures are left as they are)
+    else:
+        main()
+        kmer_path()

@@ -27,7 +27,8 @@ def test_reference_unit_scenarios_through_shims(tmp_path):
     build.build()
     exe = g.build_shim_test()
     out = tmp_path / "parallel.bf"
-    r = subprocess.run([exe, GOLDEN, str(out)], capture_output=True, text=True, timeout=600,
+    swig_out = tmp_path / "swig_test_pl.bf"
+    r = subprocess.run([exe, GOLDEN, str(out), str(swig_out)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, OMP_NUM_THREADS="8"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all shim tests passed" in r.stdout
@@ -41,6 +42,9 @@ def test_reference_unit_scenarios_through_shims(tmp_path):
     data = out.read_bytes()
     body = data[data.index(b"[HeaderEnd]\n") + len(b"[HeaderEnd]\n"):]
     assert len(body) == g["bits"] // 8 and hashlib.sha256(body).hexdigest() == g["body_sha256"]
+    # the file swig/test.pl stores (k = 20 raw k-mers through KmerBloomFilter::insert(const char*)) is the reference's
+    t = load_golden("kmer_path.json")["swig_test_pl"]
+    assert hashlib.sha256(swig_out.read_bytes()).hexdigest() == t["file_sha256"]
 
 
 @pytest.mark.gpu

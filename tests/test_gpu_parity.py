@@ -816,6 +816,90 @@ def test_swig_surface_kmer_bloom_filter(bf, oracle, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------
+# the raw-k-mer path: KmerBloomFilter::insert / contains(const char*) = NTC64(kmerSeq, k) + NTE64
+# ---------------------------------------------------------------------------------------------
+def test_kmer_path_golden_hashes(bf, oracle):
+    """every pinned k-mer case -- including k % 4 == 0 ("ub") and U ("u"), where the reference's raw-k-mer
+    path disagrees with its own iterator -- comes out of the HIP kernel with the reference's x86-64 value"""
+    n = 0
+    for case in load_golden("hash_vectors.json")["kmer"]:
+        hv, ok = bf.hash_kmers(case["kmer"].encode("latin-1"), case["h"], case["k"])
+        assert ok[0] == 1 and (hv[0] == unhex(case["hashes"], 0)).all(), case
+        n += 1
+    assert n == 37
+    n_def = 0
+    for case in load_golden("kmer_path.json")["hashes"]:
+        hv, ok = bf.hash_kmers(case["kmer"].encode("latin-1"), case["h"], case["k"])
+        assert ok[0] == case["defined"], case
+        if case["defined"]:
+            assert (hv[0] == unhex(case["hashes"], 0)).all(), case
+            n_def += 1
+        else:
+            assert not hv.any()
+    assert n_def == 173
+    # batches against the oracle: many k-mers per call, every k from 1 to 70 and a few above 256
+    rng = np.random.RandomState(8)
+    alpha = list(b"ACGT" * 5 + b"acgtUuNn\x01\x03-*")
+    for k in list(range(1, 71)) + [255, 256, 257, 300]:
+        kms = bytes(rng.choice(alpha, k * 257).tolist())
+        hv, ok = bf.hash_kmers(kms, 3, k)
+        ehv, eok = oracle.kmer_hashes(kms, k, 3)
+        assert (ok == eok).all() and (hv == ehv).all(), k
+
+
+def test_kmer_path_swig_test_pl_replay(bf, tmp_path):
+    """swig/test.pl:8-46 through the drop-in: BloomFilter(1000000000, 5, 20), four insert(kmer) calls (k % 4 == 0),
+    contains(kmer) of six k-mers, storeFilter -> the reference's file byte for byte (header, set bits, SHA-256 of
+    the 125 MB), load it again and ask the same questions"""
+    t = load_golden("kmer_path.json")["swig_test_pl"]
+    f = bf.KmerBloomFilter(t["bits"], t["h"], t["k"])
+    for km in t["inserted"]:
+        f.insert(km)
+    assert [int(f.contains(km)) for km in t["queried"]] == t["contains"]
+    assert f.containsKmers(t["queried"]).tolist() == t["contains"]
+    assert f.getPop() == t["pop"]
+    body = f.download()
+    assert sorted(int(8 * i + b) for i in np.flatnonzero(body) for b in range(8) if (body[i] >> b) & 1) == t["set_bits"]
+    path = str(tmp_path / "BloomFilter.bf")
+    f.storeFilter(path)
+    raw = open(path, "rb").read()
+    assert raw[: len(t["header"])] == t["header"].encode()
+    assert hashlib.sha256(raw).hexdigest() == t["file_sha256"]
+    g = bf.KmerBloomFilter(path=path)
+    assert [int(g.contains(km)) for km in t["queried"]] == t["contains"]
+    assert (g.getPop(), g.getHashNum(), g.getKmerSize(), g.getFilterSize()) == (t["pop"], t["h"], t["k"], t["bits"])
+    # the iterator path puts the same four k-mers elsewhere when k % 4 == 0 -- as it does in the reference
+    it = bf.KmerBloomFilter(t["bits"], t["h"], t["k"])
+    for km in t["inserted"]:
+        bf.insertSeq(it, km)
+    assert it.compare(f)[0] > 0 and not t["same_as_iterator_path"]
+    # swig/test.pl:59-84: insertSeq, then contains(kmer) of every 5-mer
+    s = load_golden("kmer_path.json")["swig_insert_seq"]
+    b = bf.KmerBloomFilter(s["bits"], s["h"], s["k"])
+    bf.insertSeq(b, s["seq"], s["h"], s["k"])
+    assert hashlib.sha256(b.download().tobytes()).hexdigest() == s["body_sha256"]
+    assert [int(b.contains(s["seq"][i:i + s["k"]])) for i in range(len(s["seq"]) - s["k"] + 1)] == s["contains"]
+
+
+def test_kmer_path_batches_with_undefined_kmers(bf, oracle):
+    """batch calls; k-mers without a defined value in the reference are skipped (nothing inserted, contains 0)"""
+    rng = np.random.RandomState(9)
+    k, h, bits = 22, 3, 1 << 16
+    kms = bytes(rng.choice(list(b"ACGT" * 6 + b"UN"), k * 4000).tolist())
+    ehv, eok = oracle.kmer_hashes(kms, k, h)
+    assert 0 < eok.sum() < len(eok)
+    f = bf.KmerBloomFilter(bits, h, k)
+    f.insertKmers(np.frombuffer(kms, np.uint8))
+    mine = np.zeros(bits // 8, np.uint8)
+    oracle.bf_insert(mine, bits, h, ehv[eok == 1])
+    assert (f.download() == mine).all()
+    q = bytes(rng.choice(list(b"ACGT" * 6 + b"UN"), k * 3000).tolist()) + kms[: 500 * k]
+    qhv, qok = oracle.kmer_hashes(q, k, h)
+    exp = oracle.bf_contains(mine, bits, h, qhv) * qok
+    assert (f.containsKmers(np.frombuffer(q, np.uint8)) == exp).all() and exp[-500:].sum() == eok[:500].sum()
+
+
+# ---------------------------------------------------------------------------------------------
 # counting filter through the partitioned pipeline: incrementAll (exact, saturating) and contains()
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nbytes,k,h", [(1 << 27, 25, 3), (5 << 24, 31, 4), (1 << 30, 25, 3)])

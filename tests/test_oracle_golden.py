@@ -47,45 +47,59 @@ def test_g2_sthash_vectors(oracle):
         assert st.ravel().tolist() == case["strand"]
 
 
-def test_kmer_hashes_match_window_hashes(oracle):
-    # KmerBloomFilter's tetramer-table path (NTC64(kmer,k)+NTE64) equals the iterator's hashes
-    n = 0
+def _kmer_bytes(km):
+    return km.encode("latin-1")
+
+
+def test_kmer_path_hash_vectors(oracle):
+    """KmerBloomFilter::insert/contains(const char*) hashes a raw k-mer with NTC64(kmerSeq, k)
+    (KmerBloomFilter.hpp:47-74, vendor/nthash.hpp:394-439,460-465).  The restatement returns the reference's
+    x86-64 values in EVERY pinned case, including the two where that path disagrees with the reference's own
+    iterator: k % 4 == 0 (flag "ub": the table walk's shift by 64) and U read as A (flag "u")."""
+    n = n_ub = n_u = 0
     for case in load_golden("hash_vectors.json")["kmer"]:
-        if case["ub"] or case.get("u"):  # the reference's own two paths disagree here: pinned separately below
-            continue
+        hv, ok = oracle.kmer_hashes(_kmer_bytes(case["kmer"]), case["k"], case["h"])
+        assert ok[0] == 1 and (hv[0] == unhex(case["hashes"], 0)).all(), case
         n += 1
-        pos, hv = oracle.nthash_seq(case["kmer"].encode(), case["h"], case["k"])
-        assert pos.tolist() == [0]
-        assert (hv[0] == unhex(case["hashes"], 0)).all()
-    assert n >= 15
+        n_ub += bool(case["ub"])
+        n_u += bool(case.get("u"))
+        # ... and where the two paths of the reference agree, so do the two restatements
+        pos, it = oracle.nthash_seq(_kmer_bytes(case["kmer"]), case["h"], case["k"])
+        assert ((it[0] == hv[0]).all()) == (not case["ub"] and not case.get("u")), case
+    assert n == 37 and n_ub == 9 and n_u == 10
+    g = load_golden("kmer_path.json")["hashes"]
+    n_def = 0
+    for case in g:
+        hv, ok = oracle.kmer_hashes(_kmer_bytes(case["kmer"]), case["k"], case["h"])
+        assert ok[0] == case["defined"], case
+        if case["defined"]:
+            assert (hv[0] == unhex(case["hashes"], 0)).all(), case
+            n_def += 1
+    assert len(g) == 188 and n_def == 173
 
 
-def test_kmer_path_divergences_of_the_reference_are_pinned(oracle):
-    """KmerBloomFilter::insert/contains(const char*) hashes a raw k-mer through the 2/3/4-mer tables
-    (KmerBloomFilter.hpp:47-74, vendor/nthash.hpp:394-439,460-465) and, in two cases, does NOT return what
-    the reference's own ntHashIterator returns for the same k-mer:
-      * k % 4 == 0: the table walk shifts a 64-bit value by 64 (nthash.hpp:354-356,388-391); what g++ 11.4 on
-        x86-64 makes of it is recorded in the fixtures (flag "ub"),
-      * k-mers containing U / u: convertTab sends U to A (nthash.hpp:16-86) where the iterator's seedTab sends
-        it to T (nthash.hpp:195-228) (flag "u").
-    The drop-in always returns the iterator's hash (one hash per k-mer, whichever entry point it comes
-    through).  This test pins the reference's x86 values and the fact that they
-    differ, so that a change on either side is noticed."""
-    n_ub = n_u = n_u_as_a = 0
-    for case in load_golden("hash_vectors.json")["kmer"]:
-        if not (case["ub"] or case.get("u")):
-            continue
-        pos, hv = oracle.nthash_seq(case["kmer"].encode(), case["h"], case["k"])
-        ref_x86 = unhex(case["hashes"], 0)
-        assert pos.tolist() == [0] and not (hv[0] == ref_x86).all(), case["kmer"]
-        if case["ub"]:
-            n_ub += 1
-        else:
-            n_u += 1
-            sub = case["kmer"].replace("U", "A").replace("u", "a")
-            n_u_as_a += bool((oracle.nthash_seq(sub.encode(), case["h"], case["k"])[1][0] == ref_x86).all())
-    assert n_ub == 9 and n_u == 10
-    assert n_u_as_a >= 8  # U read as A, except where the U falls into a one-base remainder of the table walk
+def test_kmer_path_swig_test_pl_replay(oracle):
+    """swig/test.pl:8-26 builds BloomFilter(1000000000, 5, 20) from four raw k-mers (k % 4 == 0) and stores it:
+    the restatement reproduces the file the reference writes (header, set bits, SHA-256 of all 125 MB)."""
+    t = load_golden("kmer_path.json")["swig_test_pl"]
+    filt = np.zeros(t["bits"] // 8, np.uint8)
+    hv, ok = oracle.kmer_hashes(_kmer_bytes("".join(t["inserted"])), t["k"], t["h"])
+    assert ok.all()
+    oracle.bf_insert(filt, t["bits"], t["h"], hv)
+    assert sorted(int(8 * i + b) for i in np.flatnonzero(filt) for b in range(8) if (filt[i] >> b) & 1) == t["set_bits"]
+    assert oracle.bf_popcount(filt, t["bits"]) == t["pop"] == 20 and not t["same_as_iterator_path"]
+    header = oracle.bf_header(t["bits"], t["h"], t["k"], 0.0, 0, 0)
+    assert header == t["header"].encode()
+    assert hashlib.sha256(header + filt.tobytes()).hexdigest() == t["file_sha256"]
+    qh, _ = oracle.kmer_hashes(_kmer_bytes("".join(t["queried"])), t["k"], t["h"])
+    assert oracle.bf_contains(filt, t["bits"], t["h"], qh).tolist() == t["contains"]
+    s = load_golden("kmer_path.json")["swig_insert_seq"]
+    filt = np.zeros(s["bits"] // 8, np.uint8)
+    oracle.bf_insert_seq(filt, s["bits"], s["h"], s["k"], s["seq"].encode())
+    assert hashlib.sha256(filt.tobytes()).hexdigest() == s["body_sha256"]
+    kms = "".join(s["seq"][i:i + s["k"]] for i in range(len(s["seq"]) - s["k"] + 1))
+    qh, _ = oracle.kmer_hashes(_kmer_bytes(kms), s["k"], s["h"])
+    assert oracle.bf_contains(filt, s["bits"], s["h"], qh).tolist() == s["contains"]
 
 
 def _body(path):

@@ -23,6 +23,24 @@ def test_nthash_random(oracle, ref, k, h):
     assert tot > 0
 
 
+def test_kmer_path_random(oracle, ref):
+    """raw k-mers (KmerBloomFilter's NTC64(kmerSeq, k) path): k 1..300, U, lowercase, bytes that are not bases"""
+    rng = np.random.RandomState(11)
+    alpha = list(b"ACGT" * 5 + b"acgtUuNn\x01\x03-*")
+    n_ok = n_skip = 0
+    for it in range(6000):
+        k = int(rng.randint(1, 300)) if it % 10 == 0 else int(rng.randint(1, 41))
+        km = bytes(rng.choice(alpha, k).tolist())
+        hv, ok = oracle.kmer_hashes(km, k, 4)
+        if ok[0]:  # (the reference reads beyond its 2-/3-mer tables otherwise: nothing to compare)
+            assert (hv[0] == ref.kmer_hashes(km, k, 4)).all(), (km, k)
+            n_ok += 1
+        else:
+            assert k % 4 in (2, 3)
+            n_skip += 1
+    assert n_ok > 4000 and n_skip > 0
+
+
 @pytest.mark.parametrize("k,h2", [(7, 1), (7, 2), (31, 1), (31, 3)])
 def test_sthash_random(oracle, ref, k, h2):
     rng = np.random.RandomState(k + h2)
