@@ -31,6 +31,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -204,14 +205,27 @@ def traffic_for(traffic, slot, kmers_per_launch):
     return t.get("bytes_per_launch")
 
 
+def launcher_command(n_gpus, argv, port=None):
+    """the command the driver itself uses for N > 1: one rank per GPU on this node, rendezvous on 127.0.0.1"""
+    port = port or int(os.environ.get("MASTER_PORT", 29500 + os.getpid() % 2000))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: start one rank per GPU under torch.distributed.run as a CHILD
+            # process (nothing has touched the GPU yet in this one), relay its output and leave with its code
+            cmd = launcher_command(args.gpus, sys.argv[1:])
+            if os.environ.get("BTLBF_BENCH_LAUNCH_DRYRUN"):  # tests: show the command instead of running it
+                print(json.dumps(cmd))
+                sys.exit(0)
+            sys.exit(subprocess.call(cmd))
         args.gpus = world
 
     import torch

@@ -79,6 +79,7 @@ _PROTOS = {
     "btlbf_get_profile": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint), C.c_int]),
     "btlbf_set_query_mode": (C.c_int, [_P, C.c_int]),
     "btlbf_set_spaced_seeds": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_uint, C.c_uint]),
+    "btlbf_digest": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "btlbf_compare": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
     "btlbf_rank_create": (C.c_int, [C.POINTER(_P), _P]),
     "btlbf_rank_destroy": (None, [_P]),

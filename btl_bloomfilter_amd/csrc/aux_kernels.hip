@@ -310,6 +310,56 @@ hipError_t launch_popcount(const void* data, uint64_t nbytes, int mode, uint32_t
 	return hipGetLastError();
 }
 
+// ---- digest of an array, computed where it lies (btlbf_digest) -------------------------------------------
+// out[0] += sum of w_i * m_i (mod 2^64), out[1] ^= xor of mix64(w_i ^ m_i) over the non-zero 64-bit words w_i, where
+// i = word0 + (index of the word in this array) is the word's index in the WHOLE filter and m_i = mix64(i + 1) | 1.
+// Zero words contribute nothing, so the digests of shards combine (add / xor) to the digest of the whole filter
+// whatever the split.  Streaming like popcount_kernel: 16-byte loads, one pair of atomics per wave.
+__global__ __launch_bounds__(256) void digest_kernel(const uint4* data, uint64_t n_vec, uint64_t word0,
+                                                     unsigned long long* out)
+{
+	unsigned long long sum = 0, x = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec;
+	     i += (uint64_t)gridDim.x * blockDim.x) {
+		typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+		const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(data) + i);
+		const uint64_t w[2] = {((uint64_t)v.y << 32) | v.x, ((uint64_t)v.w << 32) | v.z};
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			if (w[q]) {
+				const uint64_t m = mix64(word0 + 2 * i + q + 1) | 1ull;
+				sum += w[q] * m;
+				x ^= mix64(w[q] ^ m);
+			}
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		sum += __shfl_xor(sum, o, 64);
+		x ^= __shfl_xor(x, o, 64);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (sum)
+			atomicAdd(out, sum);
+		if (x)
+			atomicXor(out + 1, x);
+	}
+}
+
+hipError_t launch_digest(const void* data, uint64_t nbytes, uint64_t word0, unsigned long long* out2, hipStream_t s)
+{
+	if (nbytes % 16)
+		return hipErrorInvalidValue;
+	const uint64_t n_vec = nbytes / 16;
+	if (n_vec == 0)
+		return hipSuccess;
+	uint64_t blocks = (n_vec + 255) / 256;
+	if (blocks > 8192)
+		blocks = 8192;
+	hipLaunchKernelGGL(digest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint4*>(data), n_vec,
+	                   word0, out2);
+	return hipGetLastError();
+}
+
 // ---- compare two arrays of the same geometry (btlbf_compare) ---------------------------------------
 // counting == 0: positions are bits; out[0] += bits that differ, out[1] += bits set only in a, out[2] += bits
 // set only in b.  counting != 0: positions are uint8_t counters; out[0] += counters that differ, out[1] +=

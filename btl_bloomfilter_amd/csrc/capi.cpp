@@ -88,6 +88,14 @@ struct btlbf_filter {
 	// and writes it (no memset of the array, no read sweep for that batch); any other entry point that touches
 	// the array zeroes it first (materialize_clear)
 	bool lazy_zero = false;
+	// the clear is ordered on the caller's stream: clear_ev is recorded there, and whichever stream carries the
+	// zeroing out (materialize_clear, or the fresh partitioned insert) waits for it first, so work that was queued
+	// before the clear on the caller's stream cannot run after (or beside) the zeroing
+	hipEvent_t clear_ev = nullptr;
+	bool clear_ev_pending = false;
+	// set once btlbf_device_ptr has handed the raw pointer out: the caller may keep it, so from then on a clear
+	// zeroes eagerly on its stream (a lazily cleared array would show stale contents through that pointer)
+	bool ptr_exposed = false;
 	ModParams mod{};
 	HashParams hp{};
 	// spaced seeds
@@ -135,14 +143,36 @@ struct FilterLock {
 	FilterLock& operator=(const FilterLock&) = delete;
 };
 
+// stream s is about to carry out a pending clear: it first waits for the point of the clear on the caller's stream
+hipError_t order_after_clear(btlbf_filter* f, hipStream_t s)
+{
+	if (!f->clear_ev_pending)
+		return hipSuccess;
+	f->clear_ev_pending = false;
+	return hipStreamWaitEvent(s, f->clear_ev, 0);
+}
+
 // a pending btlbf_clear takes effect now, on the stream of the operation that needs the array
 hipError_t materialize_clear(btlbf_filter* f, hipStream_t s)
 {
 	if (!f || !f->lazy_zero)
 		return hipSuccess;
+	hipError_t e = order_after_clear(f, s);
+	if (e != hipSuccess)
+		return e;
 	f->lazy_zero = false;
 	return hipMemsetAsync(f->d_data, 0, f->alloc_bytes, s);
 }
+
+// every launch of a kernel that reads or writes the array directly goes through this check: an entry point that
+// forgot MATERIALIZE would otherwise read uninitialised HBM (the fresh partitioned insert is the one legitimate
+// user of a lazily cleared array and does not come this way)
+#define REQUIRE_MATERIALIZED(f)                                                                               \
+	do {                                                                                                      \
+		if ((f)->lazy_zero)                                                                                   \
+			return fail(BTLBF_EINVAL, "internal error: %s line %d launches on a lazily cleared array", __func__, \
+			            __LINE__);                                                                            \
+	} while (0)
 #define MATERIALIZE(f, s)                                                                              \
 	do {                                                                                               \
 		hipError_t em__ = materialize_clear(const_cast<btlbf_filter*>(f), static_cast<hipStream_t>(s)); \
@@ -611,6 +641,8 @@ extern "C" int btlbf_destroy(btlbf_filter* f)
 	if (!f)
 		return BTLBF_OK;
 	DeviceGuard g(f->device);
+	if (f->clear_ev)
+		(void)hipEventDestroy(f->clear_ev);
 	(void)hipFree(f->d_data);
 	(void)hipFree(f->d_scalar);
 	(void)hipFree(f->d_pos_tab);
@@ -736,14 +768,18 @@ extern "C" uint64_t btlbf_get_n_entry(const btlbf_filter* f) { return f->n_entry
 extern "C" uint64_t btlbf_get_t_entry(const btlbf_filter* f) { return f->t_entry; }
 extern "C" void btlbf_set_n_entry(btlbf_filter* f, uint64_t v) { f->n_entry = v; }
 extern "C" void btlbf_set_t_entry(btlbf_filter* f, uint64_t v) { f->t_entry = v; }
-extern "C" void* btlbf_device_ptr(const btlbf_filter* f)
+extern "C" void* btlbf_device_ptr(const btlbf_filter* f_)
 {
-	if (f && f->lazy_zero) { // a caller that looks at the raw array must see a pending clear
-		FilterLock lk__(f);
+	if (!f_)
+		return nullptr;
+	btlbf_filter* f = const_cast<btlbf_filter*>(f_);
+	FilterLock lk__(f);
+	if (f->lazy_zero) { // a caller that looks at the raw array must see a pending clear
 		DeviceGuard g(f->device);
-		(void)materialize_clear(const_cast<btlbf_filter*>(f), nullptr);
+		(void)materialize_clear(f, nullptr);
 		(void)hipDeviceSynchronize();
 	}
+	f->ptr_exposed = true; // from now on btlbf_clear zeroes eagerly, on its stream: the pointer may be kept
 	return f->d_data;
 }
 extern "C" int btlbf_device(const btlbf_filter* f) { return f->device; }
@@ -753,8 +789,20 @@ extern "C" int btlbf_clear(btlbf_filter* f, void* stream)
 	FilterLock lk__(f);
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
-	(void)stream;
-	f->lazy_zero = true; // zeroed by whoever touches the array next (see btlbf_filter::lazy_zero)
+	DeviceGuard g(f->device);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (f->ptr_exposed) { // someone may hold the raw pointer: zero now, in stream order
+		f->lazy_zero = false;
+		f->clear_ev_pending = false;
+		HIP_TRY(hipMemsetAsync(f->d_data, 0, f->alloc_bytes, s));
+		return BTLBF_OK;
+	}
+	// lazy: zeroed by whoever touches the array next (see btlbf_filter::lazy_zero), after this point of `stream`
+	if (!f->clear_ev)
+		HIP_TRY(hipEventCreateWithFlags(&f->clear_ev, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(f->clear_ev, s));
+	f->clear_ev_pending = true;
+	f->lazy_zero = true;
 	return BTLBF_OK;
 }
 
@@ -1105,6 +1153,7 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 		}
 	}
 	if (!done) {
+		REQUIRE_MATERIALIZED(f);
 		ProfSpan ps(f, op == OP_BF_CONTAINS || op == OP_BF_CONTAINS_WIN ? BTLBF_PROF_QUERY_DIRECT : BTLBF_PROF_OTHER, s);
 		HIP_TRY(launch_seq_op(op, a, s));
 	}
@@ -1203,7 +1252,9 @@ bool plan_segments(uint64_t mloc, PartPlan& pl, uint32_t unit_shift = 3)
 			pl.seg_shift = (uint32_t)v - 3 + unit_shift;
 	}
 	pl.n_seg = (mloc + (1ull << pl.seg_shift) - 1) >> pl.seg_shift;
-	return pl.n_seg <= 1024ull * 1024;
+	// up to 2^20 segments: pass A x one split pass; up to 2^22 (a 256 GiB bit array and beyond): two split passes
+	// (entries stay 32-bit: 1024 level-0 bins of at most 2^32 positions)
+	return pl.n_seg <= 4096ull * 1024;
 }
 
 // append the split levels that take bins of 2^lv[0].shift positions down to segments
@@ -1331,6 +1382,8 @@ int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, in
                uint32_t bin_offset = 0, uint32_t n_bins0 = 0)
 {
 	const int exact = sd.counting && !query; // counter increments: every entry exactly once
+	if (f->lazy_zero && !(sd.fresh && !query)) // only a fresh insert may run on a lazily cleared array
+		return fail(BTLBF_EINVAL, "internal error: partition passes on a lazily cleared array");
 	const int prof_split = query ? BTLBF_PROF_QUERY_SPLIT : BTLBF_PROF_INSERT_SPLIT;
 	const int prof_apply = query ? BTLBF_PROF_QUERY_TEST : BTLBF_PROF_INSERT_APPLY;
 	if (n_bins0 == 0)
@@ -1385,7 +1438,7 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 // plan the single-GPU pipeline for a buffer and (re)allocate the scratch;
 // *ok = false means "not applicable, use the direct kernel"
 int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan& pl, PartTiling* tiling,
-                 uint8_t** extra, bool* ok)
+                 uint8_t** extra, bool* ok, int mode)
 {
 	*ok = false;
 	if (!plan_segments(f->mod.shard_len, pl, f->kind == BTLBF_COUNTING8 ? 0 : 3))
@@ -1401,8 +1454,12 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
 			if (v >= 1 && v <= 10 && ceil_log2(pl.n_seg) - v <= 10)
 				b1 = (unsigned)v;
 		}
+		if (ceil_log2(pl.n_seg) > b1 + 10)
+			b1 = ceil_log2(pl.n_seg) - 10; // pass A writes at most 1024 bins
 		l0.shift = pl.seg_shift + b1;
 		l0.bins = (uint32_t)((pl.n_seg + (1ull << b1) - 1) >> b1);
+		if (l0.shift > 32)
+			return BTLBF_OK; // (cannot happen below 2^22 segments)
 	}
 	l0.P = l0.bins;
 	l0.alloc_bins = l0.bins;
@@ -1427,6 +1484,11 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
 	}
 	if (pl.bytes_total > budget)
 		return BTLBF_OK;
+	// AUTO: a batch that the scratch budget has cut small is not worth a sweep of the array either (the rule
+	// want_partitioned applies to the whole call, applied to one batch): a filter that nearly fills the HBM
+	// leaves a few GB for scratch, and the direct kernels are then the faster path
+	if (mode == BTLBF_INSERT_AUTO && tiles < tiling->n_tiles && (double)tiles * ppt < 0.02 * (double)f->local_bytes)
+		return BTLBF_OK;
 	pl.tiles_per_batch = tiles;
 	int rc = ensure_scratch(f, pl.bytes_total, ok);
 	if (rc || !*ok)
@@ -1449,7 +1511,7 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 	uint8_t* extra = nullptr;
 	bool ok = false;
 	PartTail tail;
-	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok);
+	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok, f->insert_mode);
 	if (rc || !ok)
 		return rc;
 	const uint64_t total_tiles = tiling.n_tiles;
@@ -1463,6 +1525,7 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 			memset(&sd, 0, sizeof sd);
 			sd.counting = f->kind == BTLBF_COUNTING8;
 			if (fresh) {
+				HIP_TRY(order_after_clear(f, s)); // this batch IS the clear: after the point it was asked for
 				sd.fresh = 1;
 				sd.pos_base = f->mod.shard_lo;
 				sd.spill_count = reinterpret_cast<unsigned long long*>(extra);
@@ -1480,14 +1543,20 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 				break;
 			f->lazy_zero = false; // every segment has been written
 			unsigned long long n_spill = 0;
-			HIP_TRY(hipMemcpyAsync(&n_spill, sd.spill_count, 8, hipMemcpyDeviceToHost, s));
-			HIP_TRY(hipStreamSynchronize(s));
-			if (n_spill <= tail.spill_cap) {
+			hipError_t e = hipMemcpyAsync(&n_spill, sd.spill_count, 8, hipMemcpyDeviceToHost, s);
+			if (e == hipSuccess)
+				e = hipStreamSynchronize(s);
+			if (e == hipSuccess && n_spill <= tail.spill_cap) {
 				PartSide plain;
 				memset(&plain, 0, sizeof plain);
 				plain.counting = sd.counting;
-				HIP_TRY(launch_spill(f->d_data, sd.spill_list, n_spill, f->mod.shard_lo, f->mod.shard_len, 0, plain, s));
-				break;
+				e = launch_spill(f->d_data, sd.spill_list, n_spill, f->mod.shard_lo, f->mod.shard_len, 0, plain, s);
+				if (e == hipSuccess)
+					break;
+			}
+			if (e != hipSuccess) { // the batch is half applied: back to a defined (empty) state
+				f->lazy_zero = true;
+				return fail(BTLBF_EHIP, "fresh partitioned insert: %s", hipGetErrorString(e));
 			}
 			HIP_TRY(hipMemsetAsync(f->d_data, 0, f->alloc_bytes, s)); // start over, the ordinary way
 		}
@@ -1535,7 +1604,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	uint8_t* extra = nullptr;
 	bool ok = false;
 	PartTail tail;
-	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok);
+	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok, f->query_mode);
 	if (rc || !ok)
 		return rc;
 	const uint64_t total_tiles = tiling.n_tiles;
@@ -1586,6 +1655,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 			d.hit_bits = hit_bits;
 			d.valid_bits = nullptr;
 			d.counts = nullptr;
+			REQUIRE_MATERIALIZED(f);
 			HIP_TRY(launch_seq_op(direct_op, d, s));
 		} else if ((rc = resolve_range(f, base, hit_bits, sd.fail_list, n_fail, table, tail.table_slots, first, n, s))) {
 			return rc;
@@ -1638,7 +1708,7 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 	// expected failed probes in the whole call (at most h per missing k-mer) must stay well below
 	// what the fail list holds per batch
 	const double miss = (double)(c[0] - c[1]) / (double)c[0];
-	*yes = miss * live < 0.25 * (double)kFailCap;
+	*yes = miss * live < 0.25 * (double)part_tail(scratch_budget(f)).fail_cap;
 	return BTLBF_OK;
 }
 
@@ -1699,7 +1769,8 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 		return BTLBF_OK;
 	};
 	// what the fail list copes with / what is worth a sweep of the array, in reads
-	const double few_cold = 0.25 * (double)kFailCap / ((double)W * f->hp.h);
+	// (the list the partitioned path will really have: a small scratch budget gets a short one, part_tail)
+	const double few_cold = 0.25 * (double)part_tail(scratch_budget(f)).fail_cap / ((double)W * f->hp.h);
 	auto warm_too_few = [&](double n_warm_reads) {
 		const double wl = n_warm_reads * W * f->hp.h;
 		return wl < 0.02 * (double)f->local_bytes || wl < 4.0e6;
@@ -2209,6 +2280,7 @@ extern "C" int btlbf_insert_seqs(btlbf_filter* f, const char* seq, uint64_t len,
 		}
 	}
 	{
+		REQUIRE_MATERIALIZED(f);
 		ProfSpan ps(f, kop == OP_BF_INSERT ? BTLBF_PROF_INSERT_DIRECT : BTLBF_PROF_OTHER, s);
 		HIP_TRY(launch_seq_op(kop, a, s));
 	}
@@ -2282,6 +2354,7 @@ int run_hash_rows(btlbf_filter* f, int hop, const uint64_t* hashes, uint64_t n, 
 	int rc = ob.prepare(out, n, mem, false, s);
 	if (rc)
 		return rc;
+	REQUIRE_MATERIALIZED(f);
 	HIP_TRY(launch_hash_op(hop, f->d_data, f->mod, f->h, f->thr, d_h, n, static_cast<uint8_t*>(ob.d), serial, s));
 	if ((rc = ob.finish(s)))
 		return rc;
@@ -2537,6 +2610,24 @@ extern "C" int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out)
 	if (f && f->kind != BTLBF_COUNTING8)
 		return fail(BTLBF_EINVAL, "filtered_popcount needs a counting filter");
 	return popcount_mode(f, 2, out);
+}
+
+extern "C" int btlbf_digest(btlbf_filter* f, uint64_t* out2)
+{
+	FilterLock lk__(f);
+	if (!f || !out2)
+		return fail(BTLBF_EINVAL, "null argument");
+	// the first local position must start a 64-bit word of the whole array (shards are cut at multiples of 64)
+	const uint64_t per_word = f->kind == BTLBF_BLOOM ? 64 : 8;
+	if (f->mod.shard_lo % per_word)
+		return fail(BTLBF_EINVAL, "digest: the shard does not start on a 64-bit word of the filter");
+	DeviceGuard g(f->device);
+	MATERIALIZE(f, nullptr);
+	HIP_TRY(hipDeviceSynchronize()); // DEVICE-mode calls may have run on non-blocking user streams
+	HIP_TRY(hipMemset(f->d_scalar, 0, 16));
+	HIP_TRY(launch_digest(f->d_data, f->alloc_bytes, f->mod.shard_lo / per_word, f->d_scalar, nullptr));
+	HIP_TRY(hipMemcpy(out2, f->d_scalar, 16, hipMemcpyDeviceToHost));
+	return BTLBF_OK;
 }
 
 extern "C" int btlbf_compare(btlbf_filter* a, btlbf_filter* b, uint64_t* out3)

@@ -216,6 +216,7 @@ hipError_t launch_serial_seq_update(const SeqArgs& a, int op, const uint64_t* ha
                                     const uint8_t* valid_bits, uint8_t* out, hipStream_t s);
 hipError_t launch_popcount(const void* data, uint64_t nbytes, int mode, uint32_t threshold,
                            unsigned long long* out, hipStream_t s);
+hipError_t launch_digest(const void* data, uint64_t nbytes, uint64_t word0, unsigned long long* out2, hipStream_t s);
 hipError_t launch_compare(const void* a, const void* b, uint64_t nbytes, int counting, unsigned long long* out3,
                           hipStream_t s);
 hipError_t launch_synth(uint8_t* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t read_len,

@@ -164,6 +164,12 @@ class _Filter:
         check(self._L.btlbf_compare(self._h, other._h, out))
         return tuple(out)
 
+    def digest(self):
+        """(sum, xor) digest of the local array computed in HBM (btlbf_digest); shard digests combine by + and ^"""
+        out = (C.c_uint64 * 2)()
+        check(self._L.btlbf_digest(self._h, out))
+        return int(out[0]), int(out[1])
+
     def setInsertMode(self, mode, scratch_bytes=0):
         """'auto' | 'direct' | 'partitioned' (see btlbf_set_insert_mode)"""
         m = {"auto": 0, "direct": 1, "partitioned": 2}[mode] if isinstance(mode, str) else int(mode)
@@ -392,6 +398,27 @@ class KmerBloomFilter(BloomFilter):
             return bool(self.containsKmers(x, stream=stream)[0])
         r = super().contains(x, stream=stream)
         return bool(r[0]) if np.ndim(x) == 1 else r
+
+
+def body_digest(body, first_word=0):
+    """btlbf_digest restated with numpy over a host copy of a filter body (bytes / uint8 array): the definition in
+    include/btlbf.h, for checking a digest against bytes that are at hand"""
+    b = np.frombuffer(bytes(body), np.uint8) if not isinstance(body, np.ndarray) else body.view(np.uint8).ravel()
+    if b.size % 8:
+        b = np.concatenate([b, np.zeros(8 - b.size % 8, np.uint8)])
+    w = b.view("<u8")
+    nz = np.flatnonzero(w)
+
+    def mix(z):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+    with np.errstate(over="ignore"):
+        m = mix(nz.astype(np.uint64) + np.uint64(first_word + 1)) | np.uint64(1)
+        s = int((w[nz] * m).sum(dtype=np.uint64)) if nz.size else 0
+        x = int(np.bitwise_xor.reduce(mix(w[nz] ^ m))) if nz.size else 0
+    return s, x
 
 
 def hash_kmers(kmers, h, k, device=0):

@@ -129,16 +129,19 @@ void btlbf_set_n_entry(btlbf_filter* f, uint64_t v); /* setnEntry BloomFilter.hp
 void btlbf_set_t_entry(btlbf_filter* f, uint64_t v); /* settEntry BloomFilter.hpp:375 */
 double btlbf_get_dfpr(const btlbf_filter* f);         /* m_dFPR: the header's dFPR field (BloomFilter.hpp:83-99,277) */
 void btlbf_set_dfpr(btlbf_filter* f, double v);
-void* btlbf_device_ptr(const btlbf_filter* f);       /* the HBM array */
+void* btlbf_device_ptr(const btlbf_filter* f);       /* the HBM array (carries out a pending clear; NULL for NULL) */
 int btlbf_device(const btlbf_filter* f);
 
 /* raw array access; offset/nbytes in bytes of the local array.
-   btlbf_clear is LAZY (and so is creation: a new filter is a cleared filter): it only marks the array as
-   "all zero".  If the next thing that happens is a partitioned btlbf_insert_seqs, its first batch builds
-   every segment from zero in LDS and writes it out -- no memset sweep, no read of the old array -- and
-   anything else that looks at the array (direct insert, queries, download, store, popcount, compare,
-   shard/rank/row entry points, btlbf_device_ptr) zeroes it first, on its own stream.  Callers cannot
-   observe the difference; a caller that writes through btlbf_device_ptr gets a zeroed array. */
+   btlbf_clear is LAZY (and so is creation: a new filter is a cleared filter): it marks the array as "all zero"
+   and records the point of the clear on `stream`.  If the next thing that happens is a partitioned
+   btlbf_insert_seqs, its first batch builds every segment from zero in LDS and writes it out -- no memset
+   sweep, no read of the old array -- and anything else that looks at the array (direct insert, queries,
+   download, store, popcount, digest, compare, shard/rank/row entry points, btlbf_device_ptr) zeroes it first.
+   Whichever stream carries the zeroing out first waits for the recorded point, so work queued on `stream`
+   before the clear is never overtaken by it.  The one thing a lazy clear cannot serve is a raw pointer kept
+   from an earlier btlbf_device_ptr call: once that function has been called on a filter, its clears are eager
+   (hipMemsetAsync on `stream`). */
 int btlbf_clear(btlbf_filter* f, void* stream);
 int btlbf_upload(btlbf_filter* f, const void* host_src, uint64_t offset, uint64_t nbytes);
 int btlbf_download(const btlbf_filter* f, void* host_dst, uint64_t offset, uint64_t nbytes);
@@ -251,6 +254,16 @@ int btlbf_hash_seqs(unsigned kmer_size, unsigned hash_num, const char* const* se
  * filtered_popcount (counters >= threshold) :231-242.  Local array only for shards. */
 int btlbf_popcount(btlbf_filter* f, uint64_t* out);
 int btlbf_filtered_popcount(btlbf_filter* f, uint64_t* out);
+
+/* Position-dependent digest of the local array, computed in HBM (one streaming read, like btlbf_popcount) -- what a
+ * caller of the reference does with sha256sum on a stored .bf body, for arrays too large to keep two of, or to
+ * download.  With w_i the i-th little-endian 64-bit word of the WHOLE filter body (zero-padded at the end) and
+ * m_i = mix64(i + 1) | 1 (mix64 = the splitmix64 finaliser: z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9;
+ * z = (z ^ z >> 27) * 0x94D049BB133111EB; z ^ z >> 31):
+ *   out2[0] = sum over the non-zero words of w_i * m_i (mod 2^64),  out2[1] = xor over them of mix64(w_i ^ m_i).
+ * A shard reports its own words with their index in the whole filter, so shard digests combine by + and ^ to the
+ * digest of the unsharded filter.  Synchronises the device. */
+int btlbf_digest(btlbf_filter* f, uint64_t* out2);
 
 /* Position-wise comparison of two filters of the same kind, size (and shard range) on one device, without
  * leaving HBM -- what a caller of the reference does with two filter bodies and memcmp.  Bit filters:
