@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <map>
 #include <mutex>
 #include <string>
 #include <sys/stat.h>
@@ -224,14 +225,78 @@ struct DeviceGuard {
 	}
 };
 
+// Small device buffers of HOST-mode calls (staged sequences, result buffers, hash rows) come from a pool:
+// hipMalloc + hipFree per call cost more than the kernels of a per-read or per-k-mer call (the drop-in shims'
+// ntHashIterator, contains(kmer), insertAndCheck make one such call each).  Power-of-two size classes up to
+// 64 MiB, per device, at most 512 MiB parked.  A pooled buffer goes back only when the call that used it has
+// synchronised its stream (every HOST-mode entry point does before it returns), so no work is pending on it.
+struct DevPool {
+	static constexpr size_t kMaxClass = 64u << 20, kMaxParked = 512u << 20;
+	std::mutex mu;
+	std::map<std::pair<int, size_t>, std::vector<void*>> parked;
+	size_t parked_bytes = 0;
+	static size_t size_class(size_t n)
+	{
+		size_t c = 4096;
+		while (c < n)
+			c <<= 1;
+		return c;
+	}
+	void* take(int dev, size_t cls)
+	{
+		std::lock_guard<std::mutex> g(mu);
+		auto it = parked.find({dev, cls});
+		if (it == parked.end() || it->second.empty())
+			return nullptr;
+		void* p = it->second.back();
+		it->second.pop_back();
+		parked_bytes -= cls;
+		return p;
+	}
+	bool give(int dev, size_t cls, void* p)
+	{
+		std::lock_guard<std::mutex> g(mu);
+		if (parked_bytes + cls > kMaxParked)
+			return false;
+		parked[{dev, cls}].push_back(p);
+		parked_bytes += cls;
+		return true;
+	}
+};
+DevPool& dev_pool()
+{
+	static DevPool* pool = new DevPool(); // never destroyed: the HIP runtime may be gone by static destruction time
+	return *pool;
+}
+
 struct DevBuf {
 	void* p = nullptr;
+	size_t pooled_class = 0;
+	int pooled_dev = -1;
 	~DevBuf()
 	{
-		if (p)
-			(void)hipFree(p);
+		if (!p)
+			return;
+		if (pooled_class && dev_pool().give(pooled_dev, pooled_class, p))
+			return;
+		(void)hipFree(p);
 	}
 	hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+	// for buffers whose user synchronises its stream before this object dies (HOST-mode staging)
+	hipError_t alloc_pooled(size_t n)
+	{
+		if (n > DevPool::kMaxClass || hipGetDevice(&pooled_dev) != hipSuccess)
+			return alloc(n);
+		const size_t cls = DevPool::size_class(n ? n : 16);
+		if ((p = dev_pool().take(pooled_dev, cls)) != nullptr) {
+			pooled_class = cls;
+			return hipSuccess;
+		}
+		hipError_t e = hipMalloc(&p, cls);
+		if (e == hipSuccess)
+			pooled_class = cls;
+		return e;
+	}
 	template <class T>
 	T* as()
 	{
@@ -572,14 +637,14 @@ int make_view(SeqView& v, const char* seq, uint64_t len, const btlbf_layout* l, 
 	}
 	if (mem != BTLBF_HOST)
 		return fail(BTLBF_EINVAL, "mem must be BTLBF_HOST or BTLBF_DEVICE");
-	HIP_TRY(v.seq_buf.alloc(len + 16));
+	HIP_TRY(v.seq_buf.alloc_pooled(len + 16));
 	if (len)
 		HIP_TRY(hipMemcpyAsync(v.seq_buf.p, seq, len, hipMemcpyHostToDevice, s));
 	v.d_seq = v.seq_buf.as<uint8_t>();
 	if (l && l->starts) {
 		if (l->starts[0] != 0 || l->starts[l->n_seqs] != len)
 			return fail(BTLBF_EINVAL, "starts[0] must be 0 and starts[n_seqs] must equal len");
-		HIP_TRY(v.starts_buf.alloc((l->n_seqs + 1) * 8));
+		HIP_TRY(v.starts_buf.alloc_pooled((l->n_seqs + 1) * 8));
 		HIP_TRY(hipMemcpyAsync(v.starts_buf.p, l->starts, (l->n_seqs + 1) * 8, hipMemcpyHostToDevice, s));
 		v.lay.starts = v.starts_buf.as<uint64_t>();
 	}
@@ -1074,7 +1139,7 @@ struct OutBuf {
 			d = user;
 		} else {
 			host = user;
-			HIP_TRY(dev.alloc(nbytes));
+			HIP_TRY(dev.alloc_pooled(nbytes));
 			d = dev.p;
 		}
 		if (zero && nbytes)
@@ -2345,7 +2410,7 @@ int run_hash_rows(btlbf_filter* f, int hop, const uint64_t* hashes, uint64_t n, 
 	DevBuf hb;
 	const uint64_t* d_h = hashes;
 	if (mem == BTLBF_HOST) {
-		HIP_TRY(hb.alloc(n * f->h * 8));
+		HIP_TRY(hb.alloc_pooled(n * f->h * 8));
 		if (n)
 			HIP_TRY(hipMemcpyAsync(hb.p, hashes, n * f->h * 8, hipMemcpyHostToDevice, s));
 		d_h = hb.as<uint64_t>();
@@ -2427,13 +2492,13 @@ struct KmerRows {
 			return fail(BTLBF_EINVAL, "null kmers");
 		d_seq = reinterpret_cast<const uint8_t*>(kmers);
 		if (mem == BTLBF_HOST) {
-			HIP_TRY(seq.alloc(n * k));
+			HIP_TRY(seq.alloc_pooled(n * k));
 			if (n)
 				HIP_TRY(hipMemcpyAsync(seq.p, kmers, n * k, hipMemcpyHostToDevice, s));
 			d_seq = seq.as<uint8_t>();
 		}
-		HIP_TRY(rows.alloc(n * h * 8));
-		HIP_TRY(valid.alloc(n));
+		HIP_TRY(rows.alloc_pooled(n * h * 8));
+		HIP_TRY(valid.alloc_pooled(n));
 		HIP_TRY(launch_kmer_rows(d_seq, n, k, h, kms, rows.as<uint64_t>(), valid.as<uint8_t>(), s));
 		return BTLBF_OK;
 	}

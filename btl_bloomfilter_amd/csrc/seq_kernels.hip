@@ -69,6 +69,9 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 		(void)bitbuf;
 		(void)canon;
 		const bool pipelined = (OP == OP_BF_CONTAINS) && !SPACED && h <= kPipe;
+		// incrementMin with <= kPipe hashes: the kW*h counter words of a lane are requested together in the window
+		// walk (one memory latency per lane, not one per counter); the update follows the walk (below)
+		const bool min_piped = (OP == OP_CBF_INC_MIN) && !SPACED && h <= kPipe;
 
 		seq_lane_windows<SPACED, kW>(tile, sh, a.hp, spaced_lds, tid * kW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
 			valid_mask |= (uint32_t)ok << w;
@@ -169,6 +172,17 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 							cbf_inc_sat(words, p);
 					}
 				}
+			} else if (OP == OP_CBF_INC_MIN && min_piped) {
+				const uint32_t* words = static_cast<const uint32_t*>(a.filter);
+				canon[w] = wh.bcan;
+#pragma unroll
+				for (int i = 0; i < kPipe; ++i) {
+					if ((uint32_t)i < h) {
+						const uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
+						wordbuf[w][i] = agent_load(words + (ok ? p >> 2 : 0)); // unclean windows read word 0 (unused)
+						bitbuf[w][i] = ((uint32_t)p & 3) * 8;
+					}
+				}
 			} else if (OP == OP_CBF_INC_MIN) {
 				if (ok) {
 					uint32_t* words = static_cast<uint32_t*>(a.filter);
@@ -249,6 +263,71 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 							all &= wordbuf[w][i] >> bitbuf[w][i];
 				}
 				hit_mask |= (all & 1u) << w;
+			}
+		}
+
+		if (OP == OP_CBF_INC_MIN && min_piped) {
+			// incrementMin, CountingBloomFilter.hpp:135-162, on the words already fetched: the minimum of the k-mer's h
+			// counters, then ONE compare-and-swap per counter that was read equal to it (a counter never decreases, so
+			// one read above the minimum cannot be at it any more), all of a lane's in flight together, expected
+			// value = the word as read.  The reference's byte CAS succeeds iff the byte still holds the minimum; the
+			// word CAS here also fails when a NEIGHBOURING counter changed, so a failed one is retried for as long as
+			// its own byte still holds the minimum.  No success at all (every minimum counter was raised by someone
+			// else meanwhile): start over from fresh reads, as the reference does (:139-160).
+			uint32_t* words = static_cast<uint32_t*>(a.filter);
+			uint32_t mn[kW];
+			uint32_t prev[kW][kPipe];
+#pragma unroll
+			for (int w = 0; w < kW; ++w) {
+				mn[w] = 0xffu;
+#pragma unroll
+				for (int i = 0; i < kPipe; ++i)
+					if ((uint32_t)i < h) {
+						const uint32_t v = (wordbuf[w][i] >> bitbuf[w][i]) & 0xffu;
+						mn[w] = v < mn[w] ? v : mn[w];
+					}
+				if (!((valid_mask >> w) & 1u))
+					mn[w] = 0xffu; // nothing to do (also the saturated case, :146-149)
+			}
+#pragma unroll
+			for (int w = 0; w < kW; ++w) {
+#pragma unroll
+				for (int i = 0; i < kPipe; ++i) {
+					prev[w][i] = 0;
+					if ((uint32_t)i < h && mn[w] != 0xffu && ((wordbuf[w][i] >> bitbuf[w][i]) & 0xffu) == mn[w]) {
+						const uint64_t p = reduce_mod<POW2>(i ? extra_hash(canon[w], a.hp.kms, i) : canon[w], a.mod);
+						prev[w][i] = atomicCAS(words + (p >> 2), wordbuf[w][i], wordbuf[w][i] + (1u << bitbuf[w][i]));
+					}
+				}
+			}
+#pragma unroll
+			for (int w = 0; w < kW; ++w) {
+				if (mn[w] == 0xffu)
+					continue;
+				bool done = false;
+#pragma unroll
+				for (int i = 0; i < kPipe; ++i) {
+					if ((uint32_t)i < h && ((wordbuf[w][i] >> bitbuf[w][i]) & 0xffu) == mn[w]) {
+						uint32_t expect = wordbuf[w][i], got = prev[w][i];
+						while (got != expect && ((got >> bitbuf[w][i]) & 0xffu) == mn[w]) { // a neighbour changed: again
+							const uint64_t p = reduce_mod<POW2>(i ? extra_hash(canon[w], a.hp.kms, i) : canon[w], a.mod);
+							expect = got;
+							got = atomicCAS(words + (p >> 2), expect, expect + (1u << bitbuf[w][i]));
+						}
+						done |= got == expect;
+					}
+				}
+				while (!done) { // the reference's retry: fresh minimum, byte CAS on every counter
+					uint32_t m2 = 0xffu;
+					for (uint32_t i = 0; i < h; ++i) {
+						const uint32_t v = cbf_read_fresh(words, reduce_mod<POW2>(i ? extra_hash(canon[w], a.hp.kms, i) : canon[w], a.mod));
+						m2 = v < m2 ? v : m2;
+					}
+					if (m2 == 0xffu)
+						break;
+					for (uint32_t i = 0; i < h; ++i)
+						done |= cbf_cas_byte(words, reduce_mod<POW2>(i ? extra_hash(canon[w], a.hp.kms, i) : canon[w], a.mod), m2);
+				}
 			}
 		}
 

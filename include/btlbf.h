@@ -15,8 +15,9 @@
  *    holds a message for the last failure on the calling thread.
  *  - `mem` says where the caller's buffers live: BTLBF_HOST (pageable/pinned host memory; the
  *    library stages through its own device scratch) or BTLBF_DEVICE (HBM pointers, used as-is).
- *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work on one filter
- *    is ordered by the stream; BTLBF_HOST calls synchronise before returning.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream; BTLBF_STREAM_PER_THREAD = HIP's
+ *    per-thread default stream, which lets BTLBF_HOST calls of different host threads overlap).  Work on one
+ *    filter is ordered by the stream; BTLBF_HOST calls synchronise before returning.
  *  - threads: every entry point that takes a filter holds the filter's internal lock for its whole duration
  *    (a filter keeps device scratch between calls), so ONE filter may be driven from many host threads -- the
  *    calls are serialised, the parallelism is inside each batch call -- and different filters run
@@ -64,6 +65,9 @@ enum { BTLBF_INCREMENT_MIN = 0, BTLBF_INCREMENT_ALL = 1 };
 /* BTLBF_ORDER_SERIAL applies k-mers one after another in buffer order on a single lane: the only
  * way incrementMin is reproducible (it is order-dependent). */
 enum { BTLBF_ORDER_PARALLEL = 0, BTLBF_ORDER_SERIAL = 1 };
+
+/* hipStreamPerThread (hip_runtime_api.h), for callers that do not include the HIP headers */
+#define BTLBF_STREAM_PER_THREAD ((void*)2)
 
 typedef struct btlbf_layout {
 	const uint64_t* starts; /* n_seqs+1 offsets, or NULL */

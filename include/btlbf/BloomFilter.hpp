@@ -202,6 +202,41 @@ class BloomFilter
 		for (const auto& s : seqs)
 			insertSeq(s);
 	}
+	// back-to-back reads of exactly readLen bytes in one host buffer: one call, one copy, the partitioned pipeline
+	// when the batch is large enough (the fast path for callers that hold their reads in memory)
+	void insertReads(const char* reads, size_t len, unsigned readLen)
+	{
+		flush();
+		btlbf_layout lay;
+		lay.starts = nullptr;
+		lay.n_seqs = 0;
+		lay.read_len = readLen;
+		btlbf_shim::check(btlbf_insert_seqs(m_f, reads, len, &lay, 0, BTLBF_ORDER_PARALLEL, BTLBF_HOST, nullptr));
+	}
+	// how many k-mers of `seq` (of the reads) contains() finds; *clean (optional) = the k-mers there are
+	uint64_t countSeq(const std::string& seq, uint64_t* clean = nullptr) const
+	{
+		flush();
+		uint64_t counts[2] = {0, 0};
+		btlbf_shim::check(btlbf_contains_seqs(m_f, seq.data(), seq.size(), nullptr, nullptr, nullptr, counts, BTLBF_HOST,
+		                                      nullptr));
+		if (clean)
+			*clean = counts[0];
+		return counts[1];
+	}
+	uint64_t countReads(const char* reads, size_t len, unsigned readLen, uint64_t* clean = nullptr) const
+	{
+		flush();
+		btlbf_layout lay;
+		lay.starts = nullptr;
+		lay.n_seqs = 0;
+		lay.read_len = readLen;
+		uint64_t counts[2] = {0, 0};
+		btlbf_shim::check(btlbf_contains_seqs(m_f, reads, len, &lay, nullptr, nullptr, counts, BTLBF_HOST, nullptr));
+		if (clean)
+			*clean = counts[0];
+		return counts[1];
+	}
 	// every k-mer of a FASTA / FASTQ / one-sequence-per-line file, gzip or plain (the job of the
 	// reference's loaders Tests/AdHoc/ParallelFilter.cpp:104-122 and swig/writeBloom_rolling.cpp:18-59);
 	// perLine: every sequence line is its own sequence instead of one sequence per FASTA record

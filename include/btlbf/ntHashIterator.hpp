@@ -63,7 +63,7 @@ class ntHashIterator
 		m_valid.assign((bytes + 63) / 64, 0);
 		btlbf_shim::check(btlbf_hash_seqs(m_k, m_h, nullptr, 0, 0, m_seq.data() + start, bytes, nullptr,
 		                                  m_hashes.data(), m_valid.data(), nullptr, BTLBF_HOST,
-		                                  btlbf_shim::default_device(), nullptr));
+		                                  btlbf_shim::default_device(), BTLBF_STREAM_PER_THREAD));
 	}
 
 	// advance m_pos to the first clean window at or after it (ntHashIterator.hpp:59-86)

@@ -94,7 +94,7 @@ class stHashIterator
 			ptrs.push_back(s.c_str());
 		btlbf_shim::check(btlbf_hash_seqs(m_k, m, ptrs.data(), m_h, m_h2, m_seq.data() + start, bytes,
 		                                  nullptr, m_hashes.data(), m_valid.data(), m_stn.data(), BTLBF_HOST,
-		                                  btlbf_shim::default_device(), nullptr));
+		                                  btlbf_shim::default_device(), BTLBF_STREAM_PER_THREAD));
 	}
 
 	void seek()
