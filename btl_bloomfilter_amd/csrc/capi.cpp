@@ -304,6 +304,39 @@ struct DevBuf {
 	}
 };
 
+// A pinned, GPU-mapped mailbox per host thread for small HOST-mode calls: the kernel reads its input from and
+// writes its results to it directly (zero copy), so such a call is one launch and one stream synchronisation
+// instead of staging buffers and three or four copies.  Never freed (a thread's exit may come after the runtime's).
+struct Mailbox {
+	static constexpr size_t kBytes = 1u << 20;
+	uint8_t* host = nullptr;
+	uint8_t* dev = nullptr;
+	bool get()
+	{
+		if (host)
+			return true;
+		void* h = nullptr;
+		if (hipHostMalloc(&h, kBytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+			(void)hipGetLastError();
+			return false;
+		}
+		void* d = nullptr;
+		if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+			(void)hipGetLastError();
+			(void)hipHostFree(h);
+			return false;
+		}
+		host = static_cast<uint8_t*>(h);
+		dev = static_cast<uint8_t*>(d);
+		return true;
+	}
+};
+Mailbox& mailbox()
+{
+	static thread_local Mailbox mb;
+	return mb;
+}
+
 uint64_t srol_n(uint64_t x, unsigned s)
 {
 	uint64_t lo = x & 0x1FFFFFFFFULL, hi = x >> 33;
@@ -1172,6 +1205,48 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 	DeviceGuard g(f->device);
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	MATERIALIZE(f, s);
+	// a short sequence from host memory (the shims' per-read containsSeq / countSeq): through the calling thread's
+	// pinned mailbox with the direct kernel -- one launch, one synchronisation, no staging (such a batch is far
+	// below what the partitioned path takes)
+	{
+		const uint64_t up16 = ~(uint64_t)15, bm = (bitmap_bytes(len) + 15) & up16;
+		const uint64_t o_hit = (len + 16 + 15) & up16, o_valid = o_hit + bm, o_cnt = o_valid + bm, o_min = o_cnt + 16,
+		               o_end = o_min + ((len + 15) & up16);
+		if (mem == BTLBF_HOST && len && len <= 65536 && (!layout || !layout->starts) && o_end <= Mailbox::kBytes &&
+		    mailbox().get()) {
+			if ((rc = check_layout(layout, len)))
+				return rc;
+			Mailbox& mb = mailbox();
+			memcpy(mb.host, seq, len);
+			SeqView v;
+			v.d_seq = mb.dev;
+			v.lay.read_len = layout ? layout->read_len : 0;
+			SeqArgs a = base_args(f, v, len);
+			// {clean windows, hits} are counted on the host from the two bitmaps (no atomics into host memory)
+			a.hit_bits = hit_bits || counts ? mb.dev + o_hit : nullptr;
+			a.valid_bits = valid_bits || counts ? mb.dev + o_valid : nullptr;
+			a.min_out = min_out ? mb.dev + o_min : nullptr;
+			REQUIRE_MATERIALIZED(f);
+			HIP_TRY(launch_seq_op(op, a, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			if (hit_bits)
+				memcpy(hit_bits, mb.host + o_hit, bitmap_bytes(len));
+			if (valid_bits)
+				memcpy(valid_bits, mb.host + o_valid, bitmap_bytes(len));
+			if (counts) {
+				counts[0] = counts[1] = 0;
+				const uint64_t* hb = reinterpret_cast<const uint64_t*>(mb.host + o_hit);
+				const uint64_t* vb = reinterpret_cast<const uint64_t*>(mb.host + o_valid);
+				for (uint64_t i = 0; i < bitmap_bytes(len) / 8; ++i) {
+					counts[0] += (uint64_t)__builtin_popcountll(vb[i]);
+					counts[1] += (uint64_t)__builtin_popcountll(hb[i]);
+				}
+			}
+			if (min_out)
+				memcpy(min_out, mb.host + o_min, len);
+			return BTLBF_OK;
+		}
+	}
 	SeqView v;
 	rc = make_view(v, seq, len, layout, mem, s);
 	if (rc)
@@ -2407,6 +2482,20 @@ int run_hash_rows(btlbf_filter* f, int hop, const uint64_t* hashes, uint64_t n, 
 	DeviceGuard g(f->device);
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	MATERIALIZE(f, s);
+	// a few rows from host memory (the shims' per-k-mer contains / insertAndCheck / minCount): through the calling
+	// thread's pinned mailbox -- no staging buffers, no copies, one launch and one synchronisation
+	const uint64_t row_bytes = (n * f->h * 8 + 15) & ~(uint64_t)15;
+	if (mem == BTLBF_HOST && n && row_bytes + n <= Mailbox::kBytes && mailbox().get()) {
+		Mailbox& mb = mailbox();
+		memcpy(mb.host, hashes, n * f->h * 8);
+		REQUIRE_MATERIALIZED(f);
+		HIP_TRY(launch_hash_op(hop, f->d_data, f->mod, f->h, f->thr, reinterpret_cast<const uint64_t*>(mb.dev), n,
+		                       out ? mb.dev + row_bytes : nullptr, serial, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		if (out)
+			memcpy(out, mb.host + row_bytes, n);
+		return BTLBF_OK;
+	}
 	DevBuf hb;
 	const uint64_t* d_h = hashes;
 	if (mem == BTLBF_HOST) {
@@ -2613,6 +2702,36 @@ extern "C" int btlbf_hash_seqs(unsigned kmer_size, unsigned hash_num, const char
 		if (rc)
 			return rc;
 	}
+	if (!hashes)
+		return fail(BTLBF_EINVAL, "null hashes output");
+	// small host-memory calls of plain ntHash (the drop-in ntHashIterator makes one per read): through the
+	// calling thread's mailbox -- the kernel reads the bases from and writes the hash rows to pinned host memory
+	const uint64_t up16 = ~(uint64_t)15;
+	const uint64_t o_h = (len + 16 + 15) & up16, o_v = o_h + ((len * hash_num * 8 + 15) & up16),
+	               o_end = o_v + ((bitmap_bytes(len) + 15) & up16);
+	if (mem == BTLBF_HOST && !seeds && !strand_bits && len && (!layout || !layout->starts) && o_end <= Mailbox::kBytes &&
+	    mailbox().get()) {
+		int rc = check_layout(layout, len);
+		if (rc)
+			return rc;
+		Mailbox& mb = mailbox();
+		memcpy(mb.host, seq, len);
+		SeqArgs a;
+		memset(&a, 0, sizeof a);
+		a.seq = mb.dev;
+		a.len = len;
+		a.layout.read_len = layout ? layout->read_len : 0;
+		a.hp = hp;
+		fill_mod(a.mod, 8, 0, 8);
+		a.hashes = reinterpret_cast<uint64_t*>(mb.dev + o_h);
+		a.valid_bits = valid_bits ? mb.dev + o_v : nullptr;
+		HIP_TRY(launch_seq_op(OP_HASH_ONLY, a, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		memcpy(hashes, mb.host + o_h, len * hash_num * 8);
+		if (valid_bits)
+			memcpy(valid_bits, mb.host + o_v, bitmap_bytes(len));
+		return BTLBF_OK;
+	}
 	SeqView v;
 	int rc = make_view(v, seq, len, layout, mem, s);
 	if (rc)
@@ -2634,8 +2753,6 @@ extern "C" int btlbf_hash_seqs(unsigned kmer_size, unsigned hash_num, const char
 	a.hashes = static_cast<uint64_t*>(ob_h.d);
 	a.valid_bits = static_cast<uint8_t*>(ob_v.d);
 	a.strand_bits = static_cast<uint64_t*>(ob_s.d);
-	if (!a.hashes)
-		return fail(BTLBF_EINVAL, "null hashes output");
 	HIP_TRY(launch_seq_op(OP_HASH_ONLY, a, s));
 	if ((rc = ob_h.finish(s)) || (rc = ob_v.finish(s)) || (rc = ob_s.finish(s)))
 		return rc;

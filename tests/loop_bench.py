@@ -18,9 +18,9 @@ REF = os.path.join(ROOT, "oracle", "_ref", "loop_bench_ref")
 SHIM = os.path.join(ROOT, "tests", "cpp", "loop_bench_shim")
 
 
-def run(exe, mode, n_reads, log2_bits, threads):
-    r = subprocess.run([exe, mode, str(n_reads), str(log2_bits), str(threads)], capture_output=True, text=True,
-                       timeout=1500)
+def run(exe, mode, n_reads, log2_bits, threads, n_query=None):
+    cmd = [exe, mode, str(n_reads), str(log2_bits), str(threads)] + ([str(n_query)] if n_query else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     if r.returncode != 0:
         return {"error": (r.stdout + r.stderr)[-400:], "mode": mode, "threads": threads}
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -44,7 +44,9 @@ def main():
                 print(json.dumps(out["runs"][-1]), file=sys.stderr, flush=True)
         for mode in ("kmer", "seq", "batch"):
             n = n_reads if (threads > 1 or mode != "kmer") else max(n_reads // 10, 1000)
-            out["runs"].append(run(SHIM, mode, n, log2_bits, threads))
+            # per-k-mer contains() / per-read countSeq through the shims: one GPU round trip each -- a sample
+            nq = {"kmer": 500 * threads, "seq": 20000 * threads}.get(mode)
+            out["runs"].append(run(SHIM, mode, n, log2_bits, threads, nq))
             print(json.dumps(out["runs"][-1]), file=sys.stderr, flush=True)
     full = [r for r in out["runs"] if r.get("reads") == n_reads]
     pops = {r["pop"] for r in full}
