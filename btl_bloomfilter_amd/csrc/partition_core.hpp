@@ -69,6 +69,14 @@ __device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
 	}
 }
 
+// diagnostic build (-DBTLBF_EXP_NOBARRIER, tools/passa_time.py): the two barriers of a partition round are left
+// out -- the output is garbage (in bounds), the time is what the round would cost if its phases could overlap freely
+#ifdef BTLBF_EXP_NOBARRIER
+#define PART_ROUND_BARRIER() __builtin_amdgcn_wave_barrier()
+#else
+#define PART_ROUND_BARRIER() __syncthreads()
+#endif
+
 #ifdef BTLBF_PHASE_STAMPS
 #define STAMP(i)                                               \
 	do {                                                       \
@@ -158,7 +166,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 			}
 		}
 	}
-	__syncthreads();
+	PART_ROUND_BARRIER();
 	STAMP(4);
 	{
 		// bins are owned by lanes (P <= NT): wave v owns bins [v*bpw, (v+1)*bpw) and flushes them itself,
@@ -222,7 +230,7 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 			}
 		}
 	}
-	__syncthreads();
+	PART_ROUND_BARRIER();
 	STAMP(6);
 	// entries that did not fit before the flush: into the freed ring space, else overflow
 	if (any_late) {

@@ -30,6 +30,12 @@ def main():
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     log2_bits = int(sys.argv[2]) if len(sys.argv) > 2 else 33
     cores = len(os.sched_getaffinity(0))
+    try:  # the cgroup CPU quota, as bench.py's cpu_baseline counts cores
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     if not os.path.exists(SHIM):
         sys.path.insert(0, ROOT)
         import __graft_entry__ as g
