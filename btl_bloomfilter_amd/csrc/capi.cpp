@@ -1357,6 +1357,10 @@ struct PartPlan {
 	PartLevel lv[3];
 	uint64_t tiles_per_batch = 0;
 	uint64_t bytes_total = 0;
+	// pass A's overlapped schedule parks the entries that find their ring full in a list per workgroup and round
+	// parity (part_hash_inst.hip): [regions][2][late_cap] two-word entries behind the tail of the scratch
+	uint2* late_buf = nullptr;
+	uint32_t late_cap = 0;
 };
 
 // chunks a region needs for `mean_entries` expected entries (Poisson: mean + 8 sigma) plus the
@@ -1609,7 +1613,10 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
 	*tiling = part_tiling(f->hp, l0.P, base.layout, base.len);
 	const uint64_t budget = scratch_budget(f);
 	*tail = part_tail(budget);
-	const uint64_t extra_bytes = tail->bytes;
+	// (a caller-imposed budget below 2 GiB keeps its scratch for the entries: pass A then runs its plain schedule)
+	pl.late_cap = budget >= (2ull << 30) ? part_late_cap(f->hp.h) : 0;
+	const uint64_t late_bytes = (uint64_t)l0.regions * 2 * pl.late_cap * sizeof(uint2);
+	const uint64_t extra_bytes = ((tail->bytes + 255) / 256) * 256 + late_bytes;
 	// a shard fed every rank's reads (ShardedBloomFilter's gather mode) keeps only its window's share
 	const double ppt = probes_per_tile(f, *tiling) * ((double)f->mod.shard_len / (double)f->mod.size);
 	uint64_t tiles = tiling->n_tiles;
@@ -1634,6 +1641,7 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
 	if (rc || !*ok)
 		return rc;
 	*extra = carve_levels(pl, static_cast<uint8_t*>(f->d_part), 0);
+	pl.late_buf = pl.late_cap ? reinterpret_cast<uint2*>(*extra + ((tail->bytes + 255) / 256) * 256) : nullptr;
 	return BTLBF_OK;
 }
 
@@ -1664,6 +1672,8 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 			PartSide sd;
 			memset(&sd, 0, sizeof sd);
 			sd.counting = f->kind == BTLBF_COUNTING8;
+			sd.late_buf = pl.late_buf;
+			sd.late_cap = pl.late_cap;
 			if (fresh) {
 				HIP_TRY(order_after_clear(f, s)); // this batch IS the clear: after the point it was asked for
 				sd.fresh = 1;
@@ -1755,6 +1765,8 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	sd.fail_cap = tail.fail_cap;
 	sd.counting = f->kind == BTLBF_COUNTING8;
 	sd.threshold = f->thr;
+	sd.late_buf = pl.late_buf;
+	sd.late_cap = pl.late_cap;
 	sd.pos_base = f->mod.shard_lo; // the fail set is keyed by global position
 	const int direct_op = sd.counting ? OP_CBF_QUERY : f->shard_count != 1 ? OP_BF_CONTAINS_WIN : OP_BF_CONTAINS;
 	uint64_t* table = sd.fail_list + tail.fail_cap;

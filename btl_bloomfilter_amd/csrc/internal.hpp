@@ -130,6 +130,7 @@ struct SeqArgs {
 	uint32_t rg_gpr;   // groups of 8 window starts per read
 	uint32_t rg_lpad;  // bytes a read occupies in the LDS tile (read_len rounded up to 8)
 	uint32_t rg_cap;   // bytes of dynamic LDS the tile image takes (reads + guard + two window bitmaps)
+	uint32_t rg_lpad_inv; // floor(2^32 / rg_lpad) + 1: x / rg_lpad == umulhi(x, rg_lpad_inv) for the offsets of a tile
 };
 
 // How pass A cuts a buffer into tiles (partition_kernels.hip: part_tiling).  All host-side planning is in
@@ -184,8 +185,11 @@ struct PartSide {
 	uint32_t fresh;                 // insert into an array known to be all zero (a pending btlbf_clear): pass C builds
 	                                // every segment from zero in LDS and writes it -- no read of the old contents,
 	                                // untouched segments are written as zeros
-	uint32_t pad_;
+	uint32_t late_cap;              // pass A's overlapped schedule: entries one workgroup may park per round ...
+	uint2* late_buf;                // ... in its two lists [workgroup][round parity][late_cap] (nullptr: plain schedule)
 };
+// entries a workgroup of pass A can produce in one round (1024 lanes x 4 windows x h): what late_cap must cover
+static inline uint32_t part_late_cap(uint32_t h) { return 1024u * 4u * h; }
 
 // launchers (defined in the .hip files)
 PartTiling part_tiling(const HashParams& hp, uint32_t p0, const LayoutParams& lay, uint64_t len);

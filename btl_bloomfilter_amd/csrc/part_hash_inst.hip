@@ -2,6 +2,8 @@
 // compiled once per hash count: -DBTLBF_PART_H=n defines launch_part_hash_h<n>.  One translation
 // unit per n keeps the build parallel (each holds 8 variants of a large kernel).
 #include "partition_core.hpp"
+#include <cstdlib>
+#include <cstring>
 
 #ifndef BTLBF_PART_H
 #error "compile with -DBTLBF_PART_H=<1..8>"
@@ -246,6 +248,275 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 	STAMP_FLUSH;
 }
 
+// ---- pass A, overlapped schedule (1024 threads, at most 64 * kOvOwners level-0 bins) ------------------------------
+// The plain schedule above runs every phase of a partition round on all 16 waves at once: while everybody waits for
+// LDS atomics the vector units idle, while everybody hashes the LDS idles, and during the flush only the waves that
+// own bins work (with its two round barriers left out -- wrong results, a diagnostic build -- the kernel takes 24 %
+// less time).  Here the waves have roles.  Waves 0..7 (X) own all the bins; waves 8..15 (Y) own none and use the
+// flush phase for work that needs no ring state:
+//   round 0 of a tile (windows 0..3):  all: hash, atomics + ring writes | barrier | X: flush   Y: hash windows 4..7
+//   round 1 of a tile (windows 4..7):  X: hash; all: atomics + writes   | barrier | X: flush   Y: stage the NEXT tile
+// so Y's atomics of round 1 overlap X's hashing, Y's hashing and ALL of the tile staging overlap X's flushes, and
+// the top-of-tile staging phase (15 % of the plain schedule) is gone.  Hashing ahead overwrites the registers that
+// hold the current round's entries, and phase 3 still needs the "late" ones among them (0.8 % of the entries with 512
+// bins, but nearly every wave has one): here phase 1 PARKS the late entries in a list of the workgroup in global
+// memory (part_round_p1_park; L2 traffic) and the Y waves fetch them back before the round's second barrier and
+// work them off behind it -- no entry lives in a register across a barrier.  Same rounds, same ring protocol, same
+// output as the plain schedule (bit-identical filters: tests/test_gpu_parity.py, tools/fuzz_parity.py).
+static constexpr int kOvOwners = 8;
+
+template <int H, bool POW2, bool SPACED, bool QUERY, bool WINDOW>
+__global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const SeqArgs a, const PartOut out,
+                                                                      const uint32_t bin_shift, const PartSide sd)
+{
+	constexpr int NT = kPartThreads;
+	constexpr int kTile = NT * kPartW;
+	constexpr int NY = NT - kOvOwners * 64;                              // staging threads (the Y waves)
+	constexpr int kStageKW = ((kPartW / 4 + 1) * (NT / NY) - 1) * 4;     // StageRaw<kStageKW>: 6 words per Y thread
+	constexpr int E = kPartHalf * H;
+	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
+	__shared__ SeqShared sh;
+	__shared__ uint32_t park_cnt[2]; // parked entries of the current even / odd round
+	const uint32_t tid = threadIdx.x;
+	const uint32_t k = a.hp.k;
+	const bool isY = (tid >> 6) >= (uint32_t)kOvOwners; // uniform over a wave
+	const int32_t ytid = (int32_t)tid - kOvOwners * 64;
+	const bool grid = a.rg_reads != 0; // read grid (internal.hpp PartGrid): tiles of rg_reads whole reads
+	const uint32_t tile_cap = grid ? a.rg_cap : seq_tile_cap(kTile, k);
+	const uint32_t tile_bytes = grid ? a.rg_reads * a.layout.read_len : (uint32_t)kTile; // window starts per tile
+	uint8_t* tile = dyn;
+	uint8_t* spaced_lds = dyn + tile_cap;
+	const PartLds pl = part_carve(dyn + tile_cap + seq_spaced_bytes(a.hp), out.P);
+	part_init<kPartThreads>(pl, out.P);
+	seq_setup_tables<NT, SPACED>(sh, a.hp, spaced_lds);
+	if (tid < 2)
+		park_cnt[tid] = 0;
+	uint2* const park0 = sd.late_buf + (uint64_t)blockIdx.x * 2 * sd.late_cap; // this workgroup's two lists
+
+	uint32_t* words = static_cast<uint32_t*>(a.filter);
+	const uint32_t ent_mask = bin_shift >= 32 ? 0xffffffffu : (1u << bin_shift) - 1;
+	// a power-of-two filter taken whole: bin and entry are bit fields of the hash itself (no 64-bit `& mask` first)
+	const uint32_t bin_mask = (uint32_t)(a.mod.mask >> bin_shift);
+	const uint32_t ent_mask_p2 = ent_mask & (uint32_t)a.mod.mask; // a filter smaller than one bin
+	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, ((uint64_t)b << bin_shift) | v); };
+	const uint64_t out_bytes = ((a.len + 63) / 64) * 8;
+	uint32_t my_valid = 0;
+
+	const uint64_t t_begin = a.first_tile + (uint64_t)blockIdx.x * a.tiles_per_block;
+	uint64_t t_end = t_begin + a.tiles_per_block;
+	if (t_end > a.first_tile + a.n_tiles)
+		t_end = a.first_tile + a.n_tiles;
+	const uint32_t L = a.layout.starts ? 0 : a.layout.read_len;
+	const uint32_t tile_step = L && !grid ? (uint32_t)(kTile % L) : 0;
+	uint32_t tile_off = 0; // offset of the NEXT tile to be staged inside its read (plain tiles, uniform reads)
+	if (L && t_begin < t_end && !grid)
+		tile_off = (uint32_t)((t_begin * (uint64_t)kTile) % L);
+	// grid: the lane's 8 window starts are starts 8m .. 8m+7 of read rd of the tile (the same in every tile);
+	// lanes beyond the grid look at the zeroed guard behind the last read and find no k-mer there
+	uint32_t grid_li0 = 0;
+	uint32_t* grid_bm = nullptr; // two bitmaps of the tile's window starts, used by turns
+	uint32_t grid_bm_words = 0;
+	const bool want_bits = a.valid_bits || a.hit_bits;
+	if (grid) {
+		const uint32_t rd = tid / a.rg_gpr, m = tid - rd * a.rg_gpr;
+		const bool in_grid = rd < a.rg_reads;
+		grid_li0 = in_grid ? rd * a.rg_lpad + 8 * m : a.rg_reads * a.rg_lpad;
+		grid_bm_words = ((tile_bytes / 8 + 15) / 16) * 4;
+		grid_bm = reinterpret_cast<uint32_t*>(tile + tile_cap) - 2 * grid_bm_words;
+		for (uint32_t i = tid; i < tile_cap / 4; i += NT) // pads, guard and bitmaps start as zeros
+			reinterpret_cast<uint32_t*>(tile)[i] = 0;
+	}
+	const uint32_t span = grid ? tile_bytes : (uint32_t)kTile + k - 1; // bytes a tile stages
+
+	// staging is the Y waves' job: 6 words per thread, requested behind phase 1 of the tile's second round (the X
+	// waves are still hashing then) and converted behind that round's first barrier
+	StageRaw<kStageKW> raw;
+	auto stage_request = [&](uint64_t t) { seq_stage_load<NY, kStageKW>(raw, a.seq, a.len, k, t * (uint64_t)tile_bytes, span, ytid); };
+	auto stage_convert = [&](uint64_t t) {
+		const uint64_t g0 = t * (uint64_t)tile_bytes;
+		if (grid)
+			seq_stage_convert_grid<NY, kStageKW>(raw, tile, sh, a.seq, a.len, L, a.rg_lpad, tile_bytes, g0, ytid);
+		else
+			seq_stage_convert<NY, kStageKW, false, false, true>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off,
+			                                                    span, ytid);
+		tile_off = seq_next_tile_off(tile_off, tile_step, L);
+	};
+	// ragged layout: sequence starts inside the freshly staged tile t (all threads; two barriers)
+	auto mark_starts = [&](uint64_t t) {
+		const uint64_t g0 = t * (uint64_t)tile_bytes;
+		uint64_t need = a.len > g0 ? a.len - g0 : 0;
+		if (need > span)
+			need = span;
+		seq_stage_mark_starts<NT>(tile, sh, a.layout, g0, need, (uint32_t)(reinterpret_cast<uintptr_t>(a.seq + g0) & 3));
+		__syncthreads();
+	};
+
+	__syncthreads(); // tables and partition state ready (and the grid's zeroed image)
+	if (t_begin < t_end) {
+		if (isY) {
+			stage_request(t_begin);
+			stage_convert(t_begin);
+		}
+		__syncthreads();
+		if (a.layout.starts)
+			mark_starts(t_begin);
+	}
+
+	LaneState st;
+	uint32_t bin[E], val[E];
+	uint32_t vmask = 0, live = 0;
+	uint64_t t = t_begin;
+	uint32_t li0 = 0;
+	auto on_window = [&](int w, bool ok, const WinHash<SPACED>& wh) {
+		vmask |= (uint32_t)ok << w;
+		if (w == kPartW - 1 && grid && want_bits) {
+			// the lane's byte of the window bitmap sits at bit 8m of its read: collected in LDS (this tile's
+			// bitmap; complete behind the barrier of the tile's second round) and written out whole afterwards.
+			// Its bit index rd * L + 8m is worked out from the lane's LDS offset rd * lpad + 8m each time (a multiply
+			// and a multiply-add) instead of being held: one more live register is one more spill in this kernel,
+			// and a scratch reload here would wait for the flush stores (vector memory retires in order)
+			uint32_t lo = li0;
+			asm volatile("" : "+v"(lo));
+			const uint32_t rd = __umulhi(lo, a.rg_lpad_inv);
+			if (rd < a.rg_reads) {
+				const uint32_t gb = lo - rd * (a.rg_lpad - L);
+				uint32_t* bm = grid_bm + ((t - t_begin) & 1) * grid_bm_words;
+				const uint32_t sh5 = gb & 31;
+				if (vmask << sh5)
+					atomicOr(&bm[gb >> 5], vmask << sh5);
+				if (sh5 > 24 && (vmask >> (32 - sh5))) // (never beyond the bitmap: bits past a read's last window are 0)
+					atomicOr(&bm[(gb >> 5) + 1], vmask >> (32 - sh5));
+			}
+		}
+		const int w4 = w % kPartHalf;
+		if (w4 == 0)
+			live = 0;
+		if (!WINDOW)
+			live |= (uint32_t)ok << w4;
+#pragma unroll
+		for (int i = 0; i < H; ++i) {
+			if (POW2 && !WINDOW) {
+				const uint64_t hv = wh.at(i);
+				bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
+				val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
+				continue;
+			}
+			uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
+			if (WINDOW) {
+				p -= a.mod.shard_lo;
+				live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
+			}
+			bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
+			val[w4 * H + i] = (uint32_t)p & ent_mask;
+		}
+	};
+	auto hash_lo = [&]() { seq_lane_range<SPACED, kPartW, H, 0, kPartHalf>(tile, sh, a.hp, spaced_lds, li0, st, on_window); };
+	auto hash_hi = [&]() { seq_lane_range<SPACED, kPartW, H, kPartHalf, kPartW>(tile, sh, a.hp, spaced_lds, li0, st, on_window); };
+	// the Y waves' share of phase 3: the round's parked entries, fetched before the round's second barrier (their
+	// count is final since its first) and applied behind it; one entry per Y thread, the rest (rare) in a loop
+	uint2 parked{0, 0};
+	uint32_t n_parked = 0;
+	auto park_fetch = [&](uint32_t par) {
+		uint32_t yt = (uint32_t)ytid; // laundered: the entry's address is worked out here, not kept (and spilled)
+		asm volatile("" : "+v"(yt));
+		n_parked = park_cnt[par];
+		if (n_parked > sd.late_cap)
+			n_parked = sd.late_cap;
+		if (yt < n_parked)
+			parked = part_park_load(park0 + (uint64_t)par * sd.late_cap, yt);
+	};
+	auto park_apply = [&](uint32_t par) {
+		uint32_t yt = (uint32_t)ytid;
+		asm volatile("" : "+v"(yt));
+		if (yt < n_parked)
+			part_park_apply(pl, parked, ovf);
+		for (uint32_t i = yt + NY; i < n_parked; i += NY)
+			part_park_apply(pl, part_park_load(park0 + (uint64_t)par * sd.late_cap, i), ovf);
+	};
+
+	for (; t < t_end; ++t) {
+		const uint64_t g0 = t * (uint64_t)tile_bytes;
+		li0 = grid ? grid_li0 : tid * kPartW + (uint32_t)(reinterpret_cast<uintptr_t>(a.seq + g0) & 3);
+		vmask = 0;
+		// ---- round 0: windows 0..3 of everybody
+		hash_lo();
+		part_round_p1_park<E, WINDOW ? 1 : H>(pl, bin, val, live, &park_cnt[0], park0, sd.late_cap);
+		__syncthreads();
+		if (!isY) {
+			part_round_p2<NT, kOvOwners>(pl, out, 0, blockIdx.x, ovf);
+		} else {
+			if (ytid == 0)
+				park_cnt[1] = 0; // everybody is past the odd round's phase 3; its next entries come behind this round
+			hash_hi(); // ahead of the X waves: this wave's entries of round 1
+			park_fetch(0);
+		}
+		__syncthreads();
+		if (isY)
+			park_apply(0);
+		// ---- round 1: windows 4..7
+		if (!isY)
+			hash_hi();
+		part_round_p1_park<E, WINDOW ? 1 : H>(pl, bin, val, live, &park_cnt[1], park0 + sd.late_cap, sd.late_cap);
+		if (isY && t + 1 < t_end)
+			stage_request(t + 1); // in flight while the X waves hash: live across the barrier only
+		__syncthreads(); // nobody reads this tile's image any more
+		if (!isY) {
+			part_round_p2<NT, kOvOwners>(pl, out, 0, blockIdx.x, ovf);
+		} else {
+			if (ytid == 0)
+				park_cnt[0] = 0;
+			if (t + 1 < t_end)
+				stage_convert(t + 1);
+			park_fetch(1);
+		}
+		__syncthreads();
+		if (isY)
+			park_apply(1);
+
+		uint32_t ltid = tid; // laundered, as above: the addresses of the write-out below are per-tile work
+		asm volatile("" : "+v"(ltid));
+		if (want_bits && grid) {
+			// this tile's bitmap is complete (two barriers since the last OR); the other one -- written out a
+			// tile ago -- is cleared for the next tile
+			uint32_t* bm = grid_bm + ((t - t_begin) & 1) * grid_bm_words;
+			uint32_t* other = grid_bm + (((t - t_begin) & 1) ^ 1) * grid_bm_words;
+			const uint8_t* bm8 = reinterpret_cast<const uint8_t*>(bm);
+			const uint64_t ob0 = g0 >> 3; // tiles are whole bytes of the bitmaps
+			// the buffer's last tile also writes the (zero) bytes up to the end of the bitmaps' last 64-bit word
+			const uint64_t left = out_bytes > ob0 ? out_bytes - ob0 : 0;
+			const uint32_t n_out = g0 + tile_bytes >= a.len || left < tile_bytes / 8 ? (uint32_t)left : tile_bytes / 8;
+			for (uint32_t i = ltid; i < n_out; i += NT) {
+				const uint8_t v = i < tile_bytes / 8 ? bm8[i] : (uint8_t)0;
+				if (a.valid_bits)
+					a.valid_bits[ob0 + i] = v;
+				if (a.hit_bits)
+					a.hit_bits[ob0 + i] = v; // a query starts from "every clean window hits"
+			}
+			for (uint32_t i = ltid; i < grid_bm_words; i += NT)
+				other[i] = 0;
+		} else if (want_bits) {
+			// one byte of the per-window bitmaps per lane
+			static_assert(kPartW == 8, "one bitmap byte per lane");
+			const uint64_t ob = (g0 >> 3) + ltid;
+			if (ob < out_bytes) {
+				if (a.valid_bits)
+					a.valid_bits[ob] = (uint8_t)vmask;
+				if (a.hit_bits)
+					a.hit_bits[ob] = (uint8_t)vmask; // a query starts from "every clean window hits"
+			}
+		}
+		my_valid += __popc(vmask);
+		if (a.layout.starts && t + 1 < t_end)
+			mark_starts(t + 1);
+	}
+	part_finish<kPartThreads>(pl, out, 0, blockIdx.x, ovf);
+	if (a.counts) {
+		const uint32_t wv = wave_sum(my_valid);
+		if ((tid & 63) == 0 && wv)
+			atomicAdd(reinterpret_cast<unsigned long long*>(a.counts), (unsigned long long)wv);
+	}
+}
+
 template <int H, bool Q, bool SMALL>
 static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd,
                                 size_t dyn, hipStream_t s)
@@ -253,8 +524,24 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t b
 	const bool pow2 = a.mod.pow2 != 0, spaced = a.hp.n_seeds > 0;
 	const bool window = a.mod.shard_lo != 0 || a.mod.shard_len != a.mod.size;
 	constexpr int NT = SMALL ? kPartThreadsS : kPartThreads;
+	// the overlapped schedule: 1024 threads and bins that eight waves can own (BTLBF_PART_OVERLAP=0: the plain one)
+	static const bool ov_off = [] {
+		const char* e = getenv("BTLBF_PART_OVERLAP");
+		return e && !strcmp(e, "0");
+	}();
+	const bool overlapped = !SMALL && out.P <= 64u * kOvOwners && !ov_off && sd.late_buf != nullptr &&
+	                        sd.late_cap >= (uint32_t)(kPartThreads * kPartHalf * H);
 #define BTLBF_PLAUNCH(P, S, W)                                                                                      \
 	do {                                                                                                            \
+		if (!SMALL && overlapped) {                                                                                 \
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, S, Q, W>),   \
+			                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                \
+			if (e != hipSuccess)                                                                                    \
+				return e;                                                                                           \
+			hipLaunchKernelGGL((part_hash_ov_kernel<H, P, S, Q, W>), dim3(out.regions), dim3(NT), dyn, s, a, out,    \
+			                   bin_shift, sd);                                                                      \
+			break;                                                                                                  \
+		}                                                                                                           \
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_kernel<H, P, S, Q, W, SMALL>),    \
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                    \
 		if (e != hipSuccess)                                                                                        \

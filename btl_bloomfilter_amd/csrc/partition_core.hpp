@@ -124,15 +124,14 @@ static __device__ uint64_t g_stamp_out[16];
 // No barrier is needed after phase 3: the next round's phase 1 only touches pt (final since phase 2)
 // and ring slots behind the late ones; its phase 2 comes after its own barrier.
 // ALL: every entry of every lane exists (no `live` tests at all: the full rounds of pass B).
-template <int NT, int E, int G, bool ALL = false, class OVF>
-__device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
-                                           const uint32_t (&bin)[E], const uint32_t (&val)[E], const uint32_t live,
-                                           OVF&& ovf STAMP_ARGS)
+// Phase 1 of a round: the atomics and the ring writes of this lane's entries.  old[e] = what the atomic returned
+// (0 for an entry that does not exist); returns whether any entry of the lane found its ring full ("late").
+template <int E, int G, bool ALL = false>
+__device__ __forceinline__ bool part_round_p1(const PartLds& l, const uint32_t (&bin)[E], const uint32_t (&val)[E],
+                                              const uint32_t live, uint32_t (&old)[E])
 {
 	const uint32_t tid = threadIdx.x;
-	const uint32_t P = o.P;
 	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
-	uint32_t old[E];
 	static_assert(E <= 32 && E % G == 0, "one flag bit per entry; whole groups");
 	// bit g of `live`: the G entries of group g exist (pass A: the H probes of one clean window).
 	// All atomics of the lane are issued back to back (independent), then consumed.
@@ -166,73 +165,171 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 			}
 		}
 	}
-	PART_ROUND_BARRIER();
-	STAMP(4);
-	{
-		// bins are owned by lanes (P <= NT): wave v owns bins [v*bpw, (v+1)*bpw) and flushes them itself,
-		// through its private slice of the flush list -- no workgroup barrier in between.  With at least half
-		// as many bins as threads a wave owns 64 (spreading 512 bins over all 16 waves was measured: the same
-		// time and 5 % more instructions, because the waves without bins skip this block outright); with FEW
-		// bins -- the 64-way split passes of a multi-GPU owner -- they are spread over all waves, or one wave
-		// would flush everything (owner side of the C4 geometry: 0.65 -> 0.49 s per pass)
-		const uint32_t lane = tid & 63;
-		const uint32_t bpw = P >= NT / 2 ? 64u : (P + NT / 64 - 1) / (NT / 64);
-		const uint32_t b = (tid >> 6) * bpw + lane;
-		uint32_t nfl = 0, rd0 = 0, w0 = 0;
-		if (lane < bpw && b < P) {
-			const uint32_t w = l.pt[b];
-			const uint32_t occ = w & 0xffffu;           // ring content + everything offered this round
-			const uint32_t avail = occ < SC ? occ : SC; // entries that really sit in the ring
-			nfl = avail >> kChunkShift;
-			const uint32_t f = nfl << kChunkShift;
-			// state for the next round (see above)
-			const uint32_t tot = occ - f;
-			const uint32_t nocc = tot < SC ? tot : SC;
-			l.pt[b] = (((w >> 16) - 4 * (tot - nocc)) << 16) | nocc;
-			l.fl[b] = f;
-			if (nfl) {
-				w0 = l.written[b];
-				l.written[b] = w0 + nfl;
-				rd0 = ((w >> 18) - occ) & ring; // read position of the ring: both halves of pt grew alike
-			}
+	return any_late;
+}
+
+// Phase 1 for a schedule that must not keep the round's entries in registers across its barriers (pass A's
+// overlapped schedule): as part_round_p1, but the entries that found their ring full are PARKED -- two words each:
+// {bin | ring slot << 10 | distance behind the ring's end << 20, value} -- in a list of the workgroup in global
+// memory (0.8 % of the entries with 512 bins; L2 traffic, not HBM), one reservation per wave on an LDS counter.
+// part_park_drain works them off behind the round's second barrier.  The list holds a whole round (late_cap).
+template <int E, int G>
+__device__ __forceinline__ void part_round_p1_park(const PartLds& l, const uint32_t (&bin)[E], const uint32_t (&val)[E],
+                                                   const uint32_t live, uint32_t* park_cnt, uint2* park, uint32_t park_cap)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
+	static_assert(E <= 32 && E % G == 0, "one flag bit per entry; whole groups");
+	uint32_t old[E];
+#pragma unroll
+	for (int g = 0; g < E / G; ++g) {
+		if ((live >> g) & 1) {
+#pragma unroll
+			for (int e = g * G; e < (g + 1) * G; ++e)
+				old[e] = atomicAdd(&l.pt[bin[e]], 0x40001u);
+		} else {
+#pragma unroll
+			for (int e = g * G; e < (g + 1) * G; ++e)
+				old[e] = 0;
 		}
-		// inclusive prefix sum of nfl over the wave (DPP row shifts + row broadcasts, no LDS) -> slots
-		// in the wave's slice (64 bins * SC/kChunk items)
-		const uint32_t incl = wave_scan_incl(nfl);
-		const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-		const uint32_t slice = (tid >> 6) * ((bpw << l.sc_shift) >> kChunkShift);
-		// a flush item is (chunk of the staging area, chunk of the output array): both are worked out here, once
-		// per chunk, and the part that depends on the bin alone is the same in every round (hoisted)
-		const uint32_t cshift = l.sc_shift - kChunkShift; // log2(chunks per ring)
-		const uint32_t cbase = ((bin0 + b) * o.regions + region) * o.cap;
-		for (uint32_t c = 0; c < nfl; ++c) {
-			const uint32_t j = slice + incl - nfl + c;
-			l.flist[j] = (uint16_t)((b << cshift) + (((rd0 >> kChunkShift) + c) & (ring >> kChunkShift)));
-			l.fwc[j] = w0 + c < o.cap ? cbase + w0 + c : 0xffffffffu;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		// kChunk/4 lanes per chunk, 16 bytes per lane -> one aligned line per chunk
-		constexpr uint32_t kLanesPerChunk = kChunk / 4;
-		const uint32_t l4 = lane & (kLanesPerChunk - 1);
-		for (uint32_t j = lane / kLanesPerChunk; j < total; j += 64 / kLanesPerChunk) {
-			const uint32_t it = l.flist[slice + j], wc = l.fwc[slice + j];
-			const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[it * kChunk + l4 * 4]);
-			if (wc != 0xffffffffu) {
-				*reinterpret_cast<uint4*>(&o.ent[(uint64_t)wc * kChunk + l4 * 4]) = v;
-			} else {
-				const uint32_t fb = it >> cshift;
-				ovf(fb, v.x);
-				ovf(fb, v.y);
-				ovf(fb, v.z);
-				ovf(fb, v.w);
+	}
+	uint32_t late = 0; // bit e: entry e found its ring full
+	uint32_t* const dummy = &l.dummy[tid & 63];
+	const uint32_t stage_shift = l.sc_shift + 2, ring4 = ring << 2;
+#pragma unroll
+	for (int g = 0; g < E / G; ++g) {
+		if ((live >> g) & 1) {
+#pragma unroll
+			for (int e = g * G; e < (g + 1) * G; ++e) {
+				const bool fits = (old[e] & 0xffffu) < SC;
+				const uint32_t slot4 = (old[e] >> 16) & ring4; // byte offset inside the ring
+				uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l.stage) + ((bin[e] << stage_shift) + slot4));
+				*(fits ? dst : dummy) = val[e];
+				late |= (uint32_t)!fits << e;
 			}
 		}
 	}
-	PART_ROUND_BARRIER();
-	STAMP(6);
-	// entries that did not fit before the flush: into the freed ring space, else overflow
+	if (__any(late != 0)) {
+		const uint32_t n = __popc(late), incl = wave_scan_incl(n);
+		const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+		uint32_t base = 0;
+		if ((tid & 63) == 63)
+			base = atomicAdd(park_cnt, total);
+		base = __builtin_amdgcn_readlane(base, 63);
+		uint32_t j = base + incl - n;
+#pragma unroll
+		for (int e = 0; e < E; ++e) {
+			if ((late >> e) & 1u) {
+				const uint32_t d = (old[e] & 0xffffu) - SC; // entries beyond the ring's end ahead of this one
+				if (j < park_cap)
+					park[j] = make_uint2(bin[e] | (((old[e] >> 18) & ring) << 10) | ((d < 2047u ? d : 2047u) << 20), val[e]);
+				++j;
+			}
+		}
+	}
+}
+
+// a parked entry (read back through L2: the list is rewritten every other round, L1 may hold an old line)
+__device__ __forceinline__ uint2 part_park_load(const uint2* park, uint32_t i)
+{
+	const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(park) + i, __ATOMIC_RELAXED,
+	                                               __HIP_MEMORY_SCOPE_AGENT);
+	return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
+// phase 3 of one parked entry (as part_round_p3): into the ring space the flush freed if the entry now lies inside
+// the ring, else the overflow path
+template <class OVF>
+__device__ __forceinline__ void part_park_apply(const PartLds& l, const uint2 en, OVF&& ovf)
+{
+	const uint32_t SC = 1u << l.sc_shift;
+	const uint32_t b = en.x & 1023u, slot = (en.x >> 10) & 1023u, d = en.x >> 20;
+	const uint32_t f = l.sc_shift == kChunkShift ? SC : l.fl[b];
+	if (d < f)
+		l.stage[(b << l.sc_shift) + slot] = en.y;
+	else
+		ovf(b, en.y);
+}
+
+// Phase 2 (between the round's two barriers): the lanes that own bins flush the full chunks of their rings and
+// write the bins' state for the next round.
+// Bins are owned by lanes (P <= NT): wave v owns bins [v*bpw, (v+1)*bpw) and flushes them itself, through its
+// private slice of the flush list -- no workgroup barrier in between.  OWNERS == 0: with at least half as many bins
+// as threads a wave owns 64 (spreading 512 bins over all 16 waves was measured: the same time and 5 % more
+// instructions, because the waves without bins skip this block outright); with FEW bins -- the 64-way split passes
+// of a multi-GPU owner -- they are spread over all waves, or one wave would flush everything (owner side of the C4
+// geometry: 0.65 -> 0.49 s per pass).  OWNERS > 0: the first OWNERS waves own all bins (P <= 64 * OWNERS) and only
+// they need to come here (pass A's overlapped schedule: the other waves hash meanwhile).
+template <int NT, int OWNERS = 0, class OVF>
+__device__ __forceinline__ void part_round_p2(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
+                                              OVF&& ovf)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint32_t P = o.P;
+	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
+	const uint32_t lane = tid & 63;
+	const uint32_t bpw = OWNERS ? (P + OWNERS - 1) / OWNERS : (P >= NT / 2 ? 64u : (P + NT / 64 - 1) / (NT / 64));
+	const uint32_t b = (tid >> 6) * bpw + lane;
+	uint32_t nfl = 0, rd0 = 0, w0 = 0;
+	if (lane < bpw && b < P && (!OWNERS || (tid >> 6) < (uint32_t)OWNERS)) {
+		const uint32_t w = l.pt[b];
+		const uint32_t occ = w & 0xffffu;           // ring content + everything offered this round
+		const uint32_t avail = occ < SC ? occ : SC; // entries that really sit in the ring
+		nfl = avail >> kChunkShift;
+		const uint32_t f = nfl << kChunkShift;
+		// state for the next round (see part_round)
+		const uint32_t tot = occ - f;
+		const uint32_t nocc = tot < SC ? tot : SC;
+		l.pt[b] = (((w >> 16) - 4 * (tot - nocc)) << 16) | nocc;
+		l.fl[b] = f;
+		if (nfl) {
+			w0 = l.written[b];
+			l.written[b] = w0 + nfl;
+			rd0 = ((w >> 18) - occ) & ring; // read position of the ring: both halves of pt grew alike
+		}
+	}
+	// inclusive prefix sum of nfl over the wave (DPP row shifts + row broadcasts, no LDS) -> slots
+	// in the wave's slice (64 bins * SC/kChunk items)
+	const uint32_t incl = wave_scan_incl(nfl);
+	const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+	const uint32_t slice = (tid >> 6) * ((bpw << l.sc_shift) >> kChunkShift);
+	// a flush item is (chunk of the staging area, chunk of the output array): both are worked out here, once
+	// per chunk, and the part that depends on the bin alone is the same in every round (hoisted)
+	const uint32_t cshift = l.sc_shift - kChunkShift; // log2(chunks per ring)
+	const uint32_t cbase = ((bin0 + b) * o.regions + region) * o.cap;
+	for (uint32_t c = 0; c < nfl; ++c) {
+		const uint32_t j = slice + incl - nfl + c;
+		l.flist[j] = (uint16_t)((b << cshift) + (((rd0 >> kChunkShift) + c) & (ring >> kChunkShift)));
+		l.fwc[j] = w0 + c < o.cap ? cbase + w0 + c : 0xffffffffu;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	// kChunk/4 lanes per chunk, 16 bytes per lane -> one aligned line per chunk
+	constexpr uint32_t kLanesPerChunk = kChunk / 4;
+	const uint32_t l4 = lane & (kLanesPerChunk - 1);
+	for (uint32_t j = lane / kLanesPerChunk; j < total; j += 64 / kLanesPerChunk) {
+		const uint32_t it = l.flist[slice + j], wc = l.fwc[slice + j];
+		const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[it * kChunk + l4 * 4]);
+		if (wc != 0xffffffffu) {
+			*reinterpret_cast<uint4*>(&o.ent[(uint64_t)wc * kChunk + l4 * 4]) = v;
+		} else {
+			const uint32_t fb = it >> cshift;
+			ovf(fb, v.x);
+			ovf(fb, v.y);
+			ovf(fb, v.z);
+			ovf(fb, v.w);
+		}
+	}
+}
+
+// Phase 3 (after the second barrier): entries that did not fit before the flush go into the freed ring space,
+// else overflow.  No barrier is needed behind it (see part_round).
+template <int E, class OVF>
+__device__ __forceinline__ void part_round_p3(const PartLds& l, const uint32_t (&bin)[E], const uint32_t (&val)[E],
+                                              const uint32_t (&old)[E], const bool any_late, OVF&& ovf)
+{
+	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
 	if (any_late) {
 #pragma unroll
 		for (int e = 0; e < E; ++e) {
@@ -247,6 +344,21 @@ __device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, u
 			}
 		}
 	}
+}
+
+template <int NT, int E, int G, bool ALL = false, class OVF>
+__device__ __forceinline__ void part_round(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
+                                           const uint32_t (&bin)[E], const uint32_t (&val)[E], const uint32_t live,
+                                           OVF&& ovf STAMP_ARGS)
+{
+	uint32_t old[E];
+	const bool any_late = part_round_p1<E, G, ALL>(l, bin, val, live, old);
+	PART_ROUND_BARRIER();
+	STAMP(4);
+	part_round_p2<NT>(l, o, bin0, region, ovf);
+	PART_ROUND_BARRIER();
+	STAMP(6);
+	part_round_p3<E>(l, bin, val, old, any_late, ovf);
 	STAMP(7);
 }
 

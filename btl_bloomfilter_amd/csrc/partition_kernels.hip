@@ -595,9 +595,11 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bi
 	a.rg_gpr = g.gpr;
 	a.rg_lpad = g.lpad;
 	a.rg_cap = g.cap;
+	a.rg_lpad_inv = g.lpad ? 0xffffffffu / g.lpad + 1 : 0;
 	a.hp.use_pos_tab = fr.use_pos_tab;
 	a.tiles_per_block = (a.n_tiles + out.regions - 1) / out.regions;
-	return launch_hash_any(a, out, bin_shift, sd, fr.dyn, query, fr.small, s);
+	const size_t dyn = fr.dyn;
+	return launch_hash_any(a, out, bin_shift, sd, dyn, query, fr.small, s);
 }
 
 hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_in, uint32_t abs_first, uint32_t n_in_bins,

@@ -123,9 +123,12 @@ struct StageRaw {
 // apart from the conversion so that a kernel can have the NEXT tile's loads in flight while it works
 // on the current one (pass A of the partitioned pipeline).
 // span = bytes a tile stages (0: the NT*KW window starts plus the k-1 bases behind the last one)
+// tid_in >= 0: the staging is shared by NT threads numbered tid_in = 0 .. NT-1 that need not be the whole workgroup
+// (pass A's overlapped schedule: half of the waves stage while the others flush); KW then only sets the words
+// per thread (KW / 4 + 1) and `span` must be given.
 template <int NT, int KW = kW>
 __device__ __forceinline__ void seq_stage_load(StageRaw<KW>& raw, const uint8_t* seq, uint64_t len, uint32_t k,
-                                               uint64_t g0, uint32_t span = 0)
+                                               uint64_t g0, uint32_t span = 0, int32_t tid_in = -1)
 {
 	constexpr uint32_t kTileW = NT * KW;
 	if (span == 0)
@@ -135,7 +138,7 @@ __device__ __forceinline__ void seq_stage_load(StageRaw<KW>& raw, const uint8_t*
 	if (need > (uint64_t)span)
 		need = span;
 	const uint32_t n_words = need ? (mis + (uint32_t)need + 3) / 4 : 0;
-	uint32_t tid = threadIdx.x; // laundered: see seq_stage_convert
+	uint32_t tid = tid_in < 0 ? threadIdx.x : (uint32_t)tid_in; // laundered: see seq_stage_convert
 	asm volatile("" : "+v"(tid));
 #pragma unroll
 	for (int a = 0; a < KW / 4 + 1; ++a) {
@@ -143,6 +146,38 @@ __device__ __forceinline__ void seq_stage_load(StageRaw<KW>& raw, const uint8_t*
 		raw.w[a] = 0;
 		if (j < n_words)
 			raw.w[a] = *reinterpret_cast<const uint32_t*>(seq + g0 - mis + 4ull * j);
+	}
+}
+
+// Ragged layout: clear the "good" flag of every staged base that opens a sequence inside the tile (g0 .. g0+need).
+// All NT threads of the workgroup; contains a barrier (the staged words must all be there before flags are cleared
+// in them); the caller provides the barrier between these atomics and the first read of the tile.
+template <int NT>
+__device__ __forceinline__ void seq_stage_mark_starts(uint8_t* tile, SeqShared& sh, const LayoutParams& lay, uint64_t g0,
+                                                      uint64_t need, uint32_t mis)
+{
+	const uint64_t* starts = lay.starts;
+	const uint32_t tid = threadIdx.x;
+	// first index s with starts[s] > g0: every boundary strictly inside (g0, g0+need) matters
+	if (tid == 0) {
+		uint64_t lo = 0, hi = lay.n_seqs + 1;
+		while (lo < hi) {
+			uint64_t mid = (lo + hi) >> 1;
+			if (starts[mid] > g0)
+				hi = mid;
+			else
+				lo = mid + 1;
+		}
+		sh.start_lo = lo;
+	}
+	__syncthreads();
+	const uint64_t s_lo = sh.start_lo;
+	for (uint64_t s = s_lo + tid; s <= lay.n_seqs; s += NT) {
+		const uint64_t p = starts[s];
+		if (p >= g0 + need)
+			break;
+		const uint32_t li = (uint32_t)(p - g0) + mis;
+		atomicAnd(reinterpret_cast<uint32_t*>(tile) + (li >> 2), ~(kBaseGood << (8 * (li & 3))));
 	}
 }
 
@@ -154,19 +189,22 @@ __device__ __forceinline__ void seq_stage_load(StageRaw<KW>& raw, const uint8_t*
 // LEAD_BARRIER = false: the caller guarantees that nobody still reads the previous tile (pass A of
 // the partitioned pipeline: its last partition round ends with a barrier after the last tile read).
 // TRAIL_BARRIER = false: the caller provides the barrier between these writes and the first read.
-template <int NT, int KW = kW, bool LEAD_BARRIER = true, bool TRAIL_BARRIER = true>
+// NOSYNC: no workgroup barrier anywhere inside (the stagers are only some of the workgroup's waves, tid_in as in
+// seq_stage_load); the ragged layout's sequence starts are then left to the caller (seq_stage_mark_starts).
+template <int NT, int KW = kW, bool LEAD_BARRIER = true, bool TRAIL_BARRIER = true, bool NOSYNC = false>
 __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, uint8_t* tile, uint32_t tile_cap,
                                                       SeqShared& sh, const uint8_t* seq, uint64_t len,
                                                       const LayoutParams& lay, uint32_t k, uint64_t g0,
-                                                      uint32_t tile_off, uint32_t span = 0)
+                                                      uint32_t tile_off, uint32_t span = 0, int32_t tid_in = -1)
 {
+	static_assert(!NOSYNC || (!LEAD_BARRIER && !TRAIL_BARRIER), "no barriers at all when only some waves stage");
 	constexpr uint32_t kTileW = NT * KW;
 	if (span == 0)
 		span = kTileW + k - 1;
 	// the thread index is laundered so that the per-word LDS addresses below are recomputed every tile: left
 	// to itself the compiler hoists them out of the caller's tile loop into registers it then has to spill,
 	// and in pass A a scratch reload sits behind the previous flush's stores (vector memory retires in order)
-	uint32_t tid = threadIdx.x;
+	uint32_t tid = tid_in < 0 ? threadIdx.x : (uint32_t)tid_in;
 	asm volatile("" : "+v"(tid));
 	const uint32_t L = lay.read_len;
 	const uint64_t* starts = lay.starts;
@@ -238,29 +276,8 @@ __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, u
 			w = *reinterpret_cast<const uint32_t*>(seq + g0 - mis + 4ull * j);
 		convert(j, w);
 	}
-	if (starts) {
-		// first index s with starts[s] > g0: every boundary strictly inside (g0, g0+need) matters
-		if (tid == 0) {
-			uint64_t lo = 0, hi = lay.n_seqs + 1;
-			while (lo < hi) {
-				uint64_t mid = (lo + hi) >> 1;
-				if (starts[mid] > g0)
-					hi = mid;
-				else
-					lo = mid + 1;
-			}
-			sh.start_lo = lo;
-		}
-		__syncthreads();
-		const uint64_t s_lo = sh.start_lo;
-		for (uint64_t s = s_lo + tid; s <= lay.n_seqs; s += NT) {
-			const uint64_t p = starts[s];
-			if (p >= g0 + need)
-				break;
-			const uint32_t li = (uint32_t)(p - g0) + mis;
-			atomicAnd(reinterpret_cast<uint32_t*>(tile) + (li >> 2), ~(kBaseGood << (8 * (li & 3))));
-		}
-	}
+	if (starts && !NOSYNC)
+		seq_stage_mark_starts<NT>(tile, sh, lay, g0, need, mis);
 	if (TRAIL_BARRIER)
 		__syncthreads();
 	return mis;
@@ -274,9 +291,9 @@ __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, u
 template <int NT, int KW>
 __device__ __forceinline__ void seq_stage_convert_grid(const StageRaw<KW>& pre, uint8_t* tile, SeqShared& sh,
                                                        const uint8_t* seq, uint64_t len, uint32_t L, uint32_t lpad,
-                                                       uint32_t tile_bytes, uint64_t g0)
+                                                       uint32_t tile_bytes, uint64_t g0, int32_t tid_in = -1)
 {
-	uint32_t tid = threadIdx.x; // laundered: see seq_stage_convert
+	uint32_t tid = tid_in < 0 ? threadIdx.x : (uint32_t)tid_in; // laundered: see seq_stage_convert
 	asm volatile("" : "+v"(tid));
 	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(seq + g0) & 3);
 	uint64_t need64 = len > g0 ? len - g0 : 0;
@@ -388,68 +405,87 @@ __device__ __forceinline__ U64x2 tab16(const void* base, uint32_t byte_off)
 	return *reinterpret_cast<const U64x2*>(static_cast<const uint8_t*>(base) + byte_off);
 }
 
-// Walk the lane's KW consecutive windows (first base at LDS index li0) and call
-// f(w, clean, const WinHash<SPACED>&) for each.
+// The rolling state of a lane between two calls of seq_lane_range (the lane's windows may be walked in pieces:
+// pass A of the partitioned pipeline hashes windows 0..3 and 4..7 of a tile at different times)
+struct LaneState {
+	uint64_t fh, rh; // forward / reverse strand hash of the current window
+	uint64_t ob, ib; // the lane's outgoing (li0 .. li0+7) and incoming (li0+k .. li0+k+7) staged bases
+	uint32_t good;   // "good" bases among the window's k-1 bases behind its first
+	uint32_t first_valid;
+};
+
+// Walk windows [W0, W1) of the lane's KW consecutive windows (first base at LDS index li0) and call
+// f(w, clean, const WinHash<SPACED>&) for each.  W0 == 0 starts the walk (start-up over the first window); a later
+// call continues from the state the previous one left in `st`.
 // HS > 0: the number of hashes per window (n_seeds * h2) is known at compile time, so the spaced-seed
 // hash values stay in registers (statically indexed); HS = 0: any count, array indexed at run time.
-template <bool SPACED, int KW = kW, int HS = 0, class F>
-__device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqShared& sh, const HashParams& hp,
-                                                 const uint8_t* spaced_lds, uint32_t li0, F&& f)
+template <bool SPACED, int KW, int HS, int W0, int W1, class F>
+__device__ __forceinline__ void seq_lane_range(const uint8_t* tile, const SeqShared& sh, const HashParams& hp,
+                                               const uint8_t* spaced_lds, uint32_t li0, LaneState& st, F&& f)
 {
 	static_assert(KW <= 8, "the lane's outgoing / incoming bases are held in one 64-bit register each");
+	static_assert(0 <= W0 && W0 < W1 && W1 <= KW, "a piece of the lane's windows");
 	const uint32_t k = hp.k;
 	const uint8_t* pos_tab = spaced_lds; // 16-byte entries, entry (i, code) at byte i*128 + code*16
 	const uint16_t* dc_idx = reinterpret_cast<const uint16_t*>(spaced_lds + seq_pos_tab_bytes(hp));
 	const uint8_t* bp = tile + li0;
-	uint64_t fh = 0, rh = 0;
-	uint32_t good = 0; // "good" bases among the window's k bases (the first base's flag is taken out below)
-	uint32_t i = 0;
-	if (hp.use_pos_tab) {
-		// first window from the positional table: four bases per LDS word, one 16-byte entry and two
-		// 64-bit XORs per base
-		for (; i + 4 <= k; i += 4) {
-			const uint32_t w = lds_u32(bp + i);
-			good += __popc(w & (kBaseGood * 0x01010101u));
+	if (W0 == 0) {
+		uint64_t fh = 0, rh = 0;
+		uint32_t good = 0; // "good" bases among the window's k bases (the first base's flag is taken out below)
+		uint32_t i = 0;
+		if (hp.use_pos_tab) {
+			// first window from the positional table: four bases per LDS word, one 16-byte entry and two
+			// 64-bit XORs per base
+			for (; i + 4 <= k; i += 4) {
+				const uint32_t w = lds_u32(bp + i);
+				good += __popc(w & (kBaseGood * 0x01010101u));
 #pragma unroll
-			for (int b = 0; b < 4; ++b) {
-				const U64x2 tt = tab16(pos_tab, (i + b) * (kNumCodes * 16) + ((w >> (8 * b)) & kCodeOff));
+				for (int b = 0; b < 4; ++b) {
+					const U64x2 tt = tab16(pos_tab, (i + b) * (kNumCodes * 16) + ((w >> (8 * b)) & kCodeOff));
+					fh ^= tt.x;
+					rh ^= tt.y;
+				}
+			}
+			for (; i < k; ++i) {
+				const uint32_t e = bp[i];
+				good += (e / kBaseGood) & 1;
+				const U64x2 tt = tab16(pos_tab, i * (kNumCodes * 16) + (e & kCodeOff));
 				fh ^= tt.x;
 				rh ^= tt.y;
 			}
-		}
-		for (; i < k; ++i) {
-			const uint32_t e = bp[i];
-			good += (e / kBaseGood) & 1;
-			const U64x2 tt = tab16(pos_tab, i * (kNumCodes * 16) + (e & kCodeOff));
-			fh ^= tt.x;
-			rh ^= tt.y;
-		}
-	} else {
-		// Horner form (large k: the positional table would not fit in LDS)
-		for (; i + 4 <= k; i += 4) {
-			const uint32_t w = lds_u32(bp + i);
-			good += __popc(w & (kBaseGood * 0x01010101u));
+		} else {
+			// Horner form (large k: the positional table would not fit in LDS)
+			for (; i + 4 <= k; i += 4) {
+				const uint32_t w = lds_u32(bp + i);
+				good += __popc(w & (kBaseGood * 0x01010101u));
 #pragma unroll
-			for (int b = 0; b < 4; ++b) {
-				const U64x2 tt = tab16(sh.init_tab, (w >> (8 * b)) & kCodeOff);
+				for (int b = 0; b < 4; ++b) {
+					const U64x2 tt = tab16(sh.init_tab, (w >> (8 * b)) & kCodeOff);
+					fh = srol1(fh) ^ tt.x;
+					rh = sror1(rh) ^ tt.y;
+				}
+			}
+			for (; i < k; ++i) {
+				const uint32_t e = bp[i];
+				good += (e / kBaseGood) & 1;
+				const U64x2 tt = tab16(sh.init_tab, e & kCodeOff);
 				fh = srol1(fh) ^ tt.x;
 				rh = sror1(rh) ^ tt.y;
 			}
 		}
-		for (; i < k; ++i) {
-			const uint32_t e = bp[i];
-			good += (e / kBaseGood) & 1;
-			const U64x2 tt = tab16(sh.init_tab, e & kCodeOff);
-			fh = srol1(fh) ^ tt.x;
-			rh = sror1(rh) ^ tt.y;
-		}
+		// bases leaving (ob: li0 .. li0+7) and entering (ib: li0+k .. li0+k+7) the lane's windows
+		st.ob = lds_u64(bp);
+		st.ib = lds_u64(bp + k);
+		st.first_valid = (uint32_t)st.ob & kBaseValid;
+		st.good = good - (((uint32_t)st.ob / kBaseGood) & 1);
+		st.fh = fh;
+		st.rh = rh;
 	}
-	// bases leaving (ob: li0 .. li0+7) and entering (ib: li0+k .. li0+k+7) the lane's windows
-	const uint64_t ob = lds_u64(bp), ib = lds_u64(bp + k);
-	uint32_t first_valid = (uint32_t)ob & kBaseValid;
-	good -= ((uint32_t)ob / kBaseGood) & 1;
+	uint64_t fh = st.fh, rh = st.rh;
+	const uint64_t ob = st.ob, ib = st.ib;
+	uint32_t good = st.good, first_valid = st.first_valid;
 #pragma unroll
-	for (int w = 0; w < KW; ++w) {
+	for (int w = W0; w < W1; ++w) {
 		if (w > 0) {
 			const uint32_t eo = (uint32_t)(ob >> (8 * (w - 1))) & 0xffu;
 			const uint32_t ei = (uint32_t)(ib >> (8 * (w - 1))) & 0xffu;
@@ -512,6 +548,19 @@ __device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqS
 		}
 		f(w, ok, wh);
 	}
+	st.fh = fh;
+	st.rh = rh;
+	st.good = good;
+	st.first_valid = first_valid;
+}
+
+// all KW windows of the lane in one go (the direct kernels; pass A's original schedule)
+template <bool SPACED, int KW = kW, int HS = 0, class F>
+__device__ __forceinline__ void seq_lane_windows(const uint8_t* tile, const SeqShared& sh, const HashParams& hp,
+                                                 const uint8_t* spaced_lds, uint32_t li0, F&& f)
+{
+	LaneState st;
+	seq_lane_range<SPACED, KW, HS, 0, KW>(tile, sh, hp, spaced_lds, li0, st, f);
 }
 
 // advance "offset of the tile start inside its read" by one tile (uniform layout)
