@@ -328,8 +328,8 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	}
 	const uint32_t span = grid ? tile_bytes : (uint32_t)kTile + k - 1; // bytes a tile stages
 
-	// staging is the Y waves' job: 6 words per thread, requested behind phase 1 of the tile's second round (the X
-	// waves are still hashing then) and converted behind that round's first barrier
+	// staging is the Y waves' job: 6 words per thread, requested at the start of the tile's second round (the Y
+	// waves have no hashing to do there) and converted behind that round's first barrier
 	StageRaw<kStageKW> raw;
 	auto stage_request = [&](uint64_t t) { seq_stage_load<NY, kStageKW>(raw, a.seq, a.len, k, t * (uint64_t)tile_bytes, span, ytid); };
 	auto stage_convert = [&](uint64_t t) {
@@ -434,44 +434,64 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			part_park_apply(pl, part_park_load(park0 + (uint64_t)par * sd.late_cap, i), ovf);
 	};
 
+#ifdef BTLBF_PHASE_STAMPS
+	// diagnostic build: cycles thread 0 (an X wave) and thread 512 (a Y wave) spend working / waiting in each of
+	// the four segments of a tile (slots 0..7: X, 8..15: Y; even = work up to the barrier, odd = wait in it)
+	uint64_t ov_acc[12] = {0}, ov_last = __builtin_readcyclecounter();
+	const bool ov_me = (tid & 511) == 0;
+#define OV_STAMP(i)                                             \
+	do {                                                        \
+		if (ov_me) {                                            \
+			const uint64_t t__ = __builtin_readcyclecounter();  \
+			ov_acc[i] += t__ - ov_last;                         \
+			ov_last = t__;                                      \
+		}                                                       \
+	} while (0)
+#else
+#define OV_STAMP(i)
+#endif
 	for (; t < t_end; ++t) {
 		const uint64_t g0 = t * (uint64_t)tile_bytes;
 		li0 = grid ? grid_li0 : tid * kPartW + (uint32_t)(reinterpret_cast<uintptr_t>(a.seq + g0) & 3);
 		vmask = 0;
-		// ---- round 0: windows 0..3 of everybody
-		hash_lo();
-		part_round_p1_park<E, WINDOW ? 1 : H>(pl, bin, val, live, &park_cnt[0], park0, sd.late_cap);
-		__syncthreads();
-		if (!isY) {
-			part_round_p2<NT, kOvOwners>(pl, out, 0, blockIdx.x, ovf);
-		} else {
-			if (ytid == 0)
-				park_cnt[1] = 0; // everybody is past the odd round's phase 3; its next entries come behind this round
-			hash_hi(); // ahead of the X waves: this wave's entries of round 1
-			park_fetch(0);
+		// (unrolled: with one rolled copy of the round the register allocator spills inside the loop)
+#pragma unroll
+		for (uint32_t r = 0; r < 2; ++r) {
+			// ---- segment a: round 0 = windows 0..3 of everybody; round 1 = windows 4..7, the Y waves' are hashed already
+			if (r == 0) {
+				hash_lo();
+			} else if (!isY) {
+				hash_hi();
+			} else if (t + 1 < t_end) {
+				// the next tile's words are requested BEFORE phase 1: behind it the compiler's wait for "no vector
+				// memory operation pending" in front of the loads would also wait for the stores that park late
+				// entries, and the X waves would find the Y waves still there when they arrive at the barrier
+				stage_request(t + 1);
+			}
+			OV_STAMP(9);
+			part_round_p1_park<E, WINDOW ? 1 : H>(pl, bin, val, live, &park_cnt[r], park0 + (uint64_t)r * sd.late_cap, sd.late_cap);
+			OV_STAMP(0);
+			__syncthreads(); // (round 1: nobody reads this tile's image any more)
+			OV_STAMP(1);
+			// ---- segment b: the X waves flush; the Y waves hash ahead (round 0) or stage the next tile (round 1)
+			if (!isY) {
+				part_round_p2<NT, kOvOwners>(pl, out, 0, blockIdx.x, ovf);
+			} else {
+				if (ytid == 0)
+					park_cnt[r ^ 1] = 0; // everybody is past the other round's phase 3; its next entries come behind this round
+				if (r == 0)
+					hash_hi(); // ahead of the X waves: this wave's entries of round 1
+				else if (t + 1 < t_end)
+					stage_convert(t + 1);
+				park_fetch(r);
+			}
+			OV_STAMP(2);
+			__syncthreads();
+			OV_STAMP(3);
+			if (isY)
+				park_apply(r);
+			OV_STAMP(8);
 		}
-		__syncthreads();
-		if (isY)
-			park_apply(0);
-		// ---- round 1: windows 4..7
-		if (!isY)
-			hash_hi();
-		part_round_p1_park<E, WINDOW ? 1 : H>(pl, bin, val, live, &park_cnt[1], park0 + sd.late_cap, sd.late_cap);
-		if (isY && t + 1 < t_end)
-			stage_request(t + 1); // in flight while the X waves hash: live across the barrier only
-		__syncthreads(); // nobody reads this tile's image any more
-		if (!isY) {
-			part_round_p2<NT, kOvOwners>(pl, out, 0, blockIdx.x, ovf);
-		} else {
-			if (ytid == 0)
-				park_cnt[0] = 0;
-			if (t + 1 < t_end)
-				stage_convert(t + 1);
-			park_fetch(1);
-		}
-		__syncthreads();
-		if (isY)
-			park_apply(1);
 
 		uint32_t ltid = tid; // laundered, as above: the addresses of the write-out below are per-tile work
 		asm volatile("" : "+v"(ltid));
@@ -509,6 +529,12 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 		if (a.layout.starts && t + 1 < t_end)
 			mark_starts(t + 1);
 	}
+#ifdef BTLBF_PHASE_STAMPS
+	if (ov_me)
+		for (int i = 0; i < 12; ++i)
+			atomicAdd((unsigned long long*)&g_stamp_out[(isY ? 12 : 0) + i], (unsigned long long)ov_acc[i]);
+#endif
+#undef OV_STAMP
 	part_finish<kPartThreads>(pl, out, 0, blockIdx.x, ovf);
 	if (a.counts) {
 		const uint32_t wv = wave_sum(my_valid);
@@ -586,8 +612,8 @@ hipError_t BTLBF_CAT(launch_part_hash_h, BTLBF_PART_H)(const SeqArgs& a, const P
 #if defined(BTLBF_PHASE_STAMPS) && BTLBF_PART_H == 4
 extern "C" void btlbf_debug_stamps(uint64_t* out16)
 {
-	(void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp_out), sizeof(uint64_t) * 16);
-	uint64_t z[16] = {0};
+	(void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp_out), sizeof(uint64_t) * 32);
+	uint64_t z[32] = {0};
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_out), z, sizeof z);
 }
 #endif

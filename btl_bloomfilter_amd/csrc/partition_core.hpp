@@ -86,7 +86,7 @@ __device__ __forceinline__ void part_init(const PartLds& l, uint32_t P)
 			g_last = t__;                                      \
 		}                                                      \
 	} while (0)
-static __device__ uint64_t g_stamp_out[16];
+static __device__ uint64_t g_stamp_out[32];
 #define STAMP_DECL uint64_t g_stamp[16] = {0}, g_last = __builtin_readcyclecounter()
 #define STAMP_FLUSH                                                                                  \
 	do {                                                                                             \

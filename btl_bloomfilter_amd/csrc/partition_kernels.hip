@@ -499,9 +499,6 @@ uint32_t part_hash_regions(const HashParams& hp, uint32_t p0, uint32_t cus)
 bool part_read_grid(const HashParams& hp, uint32_t p0, const LayoutParams& lay, PartGrid* g)
 {
 	*g = PartGrid();
-#ifdef BTLBF_PHASE_STAMPS
-	return false; // the phase-stamp build of pass A times the plain staging only
-#endif
 	const uint32_t L = lay.starts ? 0 : lay.read_len, k = hp.k;
 	if (L < 16 || L < k || L > 4096 || part_want_small(p0))
 		return false;
