@@ -1770,6 +1770,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	sd.pos_base = f->mod.shard_lo; // the fail set is keyed by global position
 	const int direct_op = sd.counting ? OP_CBF_QUERY : f->shard_count != 1 ? OP_BF_CONTAINS_WIN : OP_BF_CONTAINS;
 	uint64_t* table = sd.fail_list + tail.fail_cap;
+	uint64_t* ctl = reinterpret_cast<uint64_t*>(extra + 64); // two words of stream-side control next to the fail count
 	if (counts)
 		HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
 	const uint64_t seq_tw = (uint64_t)seq_tile_windows();
@@ -1788,30 +1789,30 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 		}
 		if ((rc = run_levels(f, pl, pl.lv[0].in(), sd, 1, s)))
 			return rc;
-		unsigned long long n_fail = 0;
-		HIP_TRY(hipMemcpyAsync(&n_fail, sd.fail_count, 8, hipMemcpyDeviceToHost, s));
-		HIP_TRY(hipStreamSynchronize(s));
-		if (n_fail == 0)
-			continue;
 		// redo / refine this batch's window range with the direct kernels: their tiles that overlap the
 		// batch's bytes.  A tile more at either end is harmless: a failed position is a bit that IS clear,
-		// so clearing any window that owns it is right, and a direct redo computes the true answer
+		// so clearing any window that owns it is right, and a direct redo computes the true answer.
+		// What happens is decided on the device (GATE_*): no failed position -> nothing; up to fail_cap -> they become
+		// a hash set and one hashing pass clears the windows that own one; more -> the range is redone by the direct
+		// kernel.  All launches are issued, the ones decided against return at once: no host round trip per batch.
 		const uint64_t first = t0 * tiling.tile_bytes / seq_tw;
 		const uint64_t end_b = std::min<uint64_t>(base.len, (t0 + a.n_tiles) * (uint64_t)tiling.tile_bytes);
 		const uint64_t n = std::min<uint64_t>((end_b + seq_tw - 1) / seq_tw, seq_tiles_all) - first;
 		ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
-		if (n_fail > tail.fail_cap) {
-			SeqArgs d = base;
-			d.first_tile = first;
-			d.n_tiles = n;
-			d.hit_bits = hit_bits;
-			d.valid_bits = nullptr;
-			d.counts = nullptr;
-			REQUIRE_MATERIALIZED(f);
-			HIP_TRY(launch_seq_op(direct_op, d, s));
-		} else if ((rc = resolve_range(f, base, hit_bits, sd.fail_list, n_fail, table, tail.table_slots, first, n, s))) {
-			return rc;
-		}
+		HIP_TRY(launch_failset_auto(sd.fail_list, sd.fail_count, tail.fail_cap, table, tail.table_slots, ctl, s));
+		SeqArgs d = base;
+		d.first_tile = first;
+		d.n_tiles = n;
+		d.hit_bits = hit_bits;
+		d.valid_bits = nullptr;
+		d.counts = nullptr;
+		d.gate = ctl;
+		d.gate_mode = GATE_REDO;
+		REQUIRE_MATERIALIZED(f);
+		HIP_TRY(launch_seq_op(direct_op, d, s));
+		d.buckets = table;
+		d.gate_mode = GATE_RESOLVE;
+		HIP_TRY(launch_seq_op(OP_BF_RESOLVE, d, s));
 	}
 	if (counts) // hits = set bits of the final bitmap
 		HIP_TRY(launch_popcount(hit_bits, ((base.len + 63) / 64) * 8, 0, 0,

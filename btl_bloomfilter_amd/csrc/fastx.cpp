@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -134,61 +135,62 @@ namespace {
 // first record start at or after file offset `begin` (file_size if there is none): FASTA '>' at a line
 // start; 4-line FASTQ: a line starting with '@' whose second successor starts with '+' (a quality line
 // may start with '@', but then the line two below it is a sequence, never a '+'); plain: any line start
+// pread that is not defeated by a signal: retried on EINTR, short reads are the caller's business
+static ssize_t pread_retry(int fd, void* buf, size_t n, off_t off)
+{
+	for (;;) {
+		const ssize_t r = pread(fd, buf, n, off);
+		if (r >= 0 || errno != EINTR)
+			return r;
+	}
+}
+
+// offset of the byte behind the first '\n' at or after `from` (file_size if there is none), reading through a
+// small window that is the caller's and grows only for a line longer than it
+static uint64_t next_line(int fd, uint64_t from, uint64_t file_size, std::vector<char>& w)
+{
+	for (uint64_t at = from; at < file_size;) {
+		const ssize_t m = pread_retry(fd, w.data(), w.size(), (off_t)at);
+		if (m <= 0)
+			return file_size;
+		if (const char* q = static_cast<const char*>(memchr(w.data(), '\n', (size_t)m)))
+			return at + (uint64_t)(q - w.data()) + 1;
+		at += (uint64_t)m;
+		if (w.size() < (1u << 20))
+			w.resize(w.size() * 4); // a long line: fewer, larger reads from here on
+	}
+	return file_size;
+}
+
 uint64_t resync(int fd, uint64_t begin, int fmt, uint64_t file_size)
 {
 	if (begin == 0)
 		return 0;
 	if (begin >= file_size)
 		return file_size;
-	std::vector<char> buf(1u << 20);
+	std::vector<char> w(4096); // reads are 4 KiB (a read record) unless a line turns out to be longer
 	// 1. first line start >= begin
-	uint64_t ls = file_size;
-	for (uint64_t off = begin - 1; off < file_size;) {
-		const ssize_t n = pread(fd, buf.data(), buf.size(), (off_t)off);
-		if (n <= 0)
-			return file_size;
-		const char* nl = static_cast<const char*>(memchr(buf.data(), '\n', (size_t)n));
-		if (nl) {
-			ls = off + (uint64_t)(nl - buf.data()) + 1;
-			break;
-		}
-		off += (uint64_t)n;
-	}
+	uint64_t ls = next_line(fd, begin - 1, file_size, w);
 	// 2. advance line by line to a record start
 	while (ls < file_size) {
-		const ssize_t n = pread(fd, buf.data(), buf.size(), (off_t)ls);
-		if (n <= 0)
+		char c = 0;
+		if (pread_retry(fd, &c, 1, (off_t)ls) != 1)
 			return file_size;
-		const char* b = buf.data();
-		const char* nl1 = static_cast<const char*>(memchr(b, '\n', (size_t)n));
-		if (b[0] != '\n' && b[0] != '\r') {
+		if (c != '\n' && c != '\r') {
 			if (fmt == btlbf_fastx::PLAIN)
 				return ls;
-			if (fmt == btlbf_fastx::FASTA && b[0] == '>')
+			if (fmt == btlbf_fastx::FASTA && c == '>')
 				return ls;
-			if (fmt == btlbf_fastx::FASTQ && b[0] == '@') {
+			if (fmt == btlbf_fastx::FASTQ && c == '@') {
 				// the first byte of the line two below, however long the two lines in between are
-				uint64_t at = ls;
-				int lines = 0;
+				const uint64_t l2 = next_line(fd, ls, file_size, w);
+				const uint64_t l3 = l2 < file_size ? next_line(fd, l2, file_size, w) : file_size;
 				char c2 = 0;
-				std::vector<char> w(1u << 20);
-				while (lines < 2 && at < file_size) {
-					const ssize_t m = pread(fd, w.data(), w.size(), (off_t)at);
-					if (m <= 0)
-						break;
-					const char* q = static_cast<const char*>(memchr(w.data(), '\n', (size_t)m));
-					if (!q) {
-						at += (uint64_t)m;
-						continue;
-					}
-					at += (uint64_t)(q - w.data()) + 1;
-					++lines;
-				}
-				if (lines == 2 && at < file_size && pread(fd, &c2, 1, (off_t)at) == 1 && c2 == '+')
+				if (l3 < file_size && pread_retry(fd, &c2, 1, (off_t)l3) == 1 && c2 == '+')
 					return ls;
 			}
 		}
-		ls += nl1 ? (uint64_t)(nl1 - b) + 1 : (uint64_t)n; // next line (or keep scanning a very long one)
+		ls = next_line(fd, ls, file_size, w); // next line
 	}
 	return file_size;
 }

@@ -121,6 +121,11 @@ struct SeqArgs {
 	uint64_t* tags;
 	uint64_t bucket_cap;
 	unsigned long long* bucket_counts;
+	// stream-side control (the partitioned query's resolve step, decided on the device): gate[0] = index mask of the
+	// failed-position table (OP_BF_RESOLVE takes it from here instead of bucket_cap), low half of gate[1] = what to
+	// do; a launch with gate != nullptr returns at once unless that equals gate_mode
+	const uint64_t* gate;
+	uint32_t gate_mode;
 	// tiling: tiles [first_tile, first_tile + n_tiles) of the buffer (n_tiles == 0: all of it)
 	uint64_t first_tile;
 	uint64_t n_tiles;
@@ -207,6 +212,11 @@ hipError_t launch_part_split(void* filter, const PartIn& in, uint32_t first_in, 
 hipError_t launch_part_apply(void* filter, uint64_t local_bytes, uint32_t seg_shift, uint64_t seg_first, uint64_t n_seg,
                              const PartIn& in, const PartSide& sd, int query, hipStream_t s);
 hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t* table, uint64_t mask, hipStream_t s);
+// the same decided on the device from the fail count of a batch: ctl[0] := table mask, ctl[1] := mode | n << 32 with
+// mode 0 = no failed position (nothing to do), 1 = table built (resolve), 2 = more than fail_cap (redo directly)
+enum { GATE_NONE = 0, GATE_RESOLVE = 1, GATE_REDO = 2 };
+hipError_t launch_failset_auto(const uint64_t* fail_list, const unsigned long long* fail_count, uint64_t fail_cap,
+                               uint64_t* table, uint64_t max_slots, uint64_t* ctl, hipStream_t s);
 hipError_t launch_spill(void* filter, const uint64_t* pos, uint64_t n, uint64_t lo, uint64_t len, int test,
                         const PartSide& sd, hipStream_t s);
 hipError_t launch_seq_op(int op, const SeqArgs& a, hipStream_t s);

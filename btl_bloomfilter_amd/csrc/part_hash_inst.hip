@@ -101,20 +101,16 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 		STAMP(0);
 		// this tile's words were requested a whole tile ago; the next tile's are requested now and stay
 		// in flight while this one is hashed and partitioned
-#ifdef BTLBF_PHASE_STAMPS
-		const uint32_t mis = seq_stage_convert<NT, kPartW, false, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
-		STAMP(1); // conversion of this thread's words
-		__syncthreads();
-		STAMP(3); // waiting for the other waves
-#else
 		uint32_t mis = 0;
 		if (grid) {
 			seq_stage_convert_grid<NT, kPartW>(raw, tile, sh, a.seq, a.len, L, a.rg_lpad, tile_bytes, g0);
+			STAMP(1); // conversion of this thread's words
 			__syncthreads();
 		} else {
 			mis = seq_stage_convert<NT, kPartW, false>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off);
+			STAMP(1);
 		}
-#endif
+		STAMP(3); // waiting for the other waves
 		if (t + 1 < t_end)
 			seq_stage_load<NT, kPartW>(raw, a.seq, a.len, k, g0 + tile_bytes, span);
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
@@ -124,22 +120,7 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 		// registers across it)
 		uint32_t bin[kPartHalf * H], val[kPartHalf * H];
 		uint32_t vmask = 0, live = 0;
-#ifdef BTLBF_EXP_NOHASH
-		// diagnostic build: no hashing -- pseudo-random entries from the window index (timing of the partition alone)
-		auto fake_windows = [&](auto&& f) {
-#pragma unroll
-			for (int w = 0; w < kPartW; ++w) {
-				WinHash<SPACED> wh;
-				wh.kms = 0;
-				wh.stn = 0;
-				wh.bcan = (uint64_t)((uint32_t)(g0 + tid * kPartW + w) * 2654435761u) << 13;
-				f(w, true, wh);
-			}
-		};
-		fake_windows([&](int w, bool ok, const WinHash<SPACED>& wh) {
-#else
 		seq_lane_windows<SPACED, kPartW, H>(tile, sh, a.hp, spaced_lds, grid ? grid_li0 : tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
-#endif
 			vmask |= (uint32_t)ok << w;
 			if (w == kPartW - 1 && grid && want_bits && grid_bit != 0xffffffffu) {
 				// the lane's byte of the window bitmap sits at bit 8m of its read: collected in LDS (this
@@ -158,9 +139,6 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 				live |= (uint32_t)ok << w4;
 #pragma unroll
 			for (int i = 0; i < H; ++i) {
-#ifdef BTLBF_EXP_NOHASH
-				uint64_t p = (wh.bcan + (uint64_t)i * 0x9E3779B97F4A7C15ULL) & a.mod.mask;
-#else
 				if (POW2 && !WINDOW) {
 					const uint64_t hv = wh.at(i);
 					bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
@@ -168,7 +146,6 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 					continue;
 				}
 				uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
-#endif
 				if (WINDOW) {
 					p -= a.mod.shard_lo;
 					live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
@@ -176,17 +153,7 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 				bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
 				val[w4 * H + i] = (uint32_t)p & ent_mask;
 			}
-#ifdef BTLBF_EXP_NOPART
-			// diagnostic build: no partition -- the entries are folded into a value that is (never) stored
 			if (w4 == kPartHalf - 1) {
-#pragma unroll
-				for (int e = 0; e < kPartHalf * H; ++e)
-					my_valid += (bin[e] ^ val[e]) == 0x12345u;
-			}
-			if (false) {
-#else
-			if (w4 == kPartHalf - 1) {
-#endif
 				STAMP(2);
 				if (SMALL) {
 					// the next tile's words (requested at the top of this tile) are pinned in their registers

@@ -702,6 +702,52 @@ hipError_t launch_failset_build(const uint64_t* fail_list, uint64_t n, uint64_t*
 	return hipGetLastError();
 }
 
+// ---- the same, steered from the device (no host round trip between a batch's test pass and its resolve step) ----
+__global__ void failset_plan_kernel(const unsigned long long* fail_count, uint64_t fail_cap, uint64_t max_slots, uint64_t* ctl)
+{
+	const uint64_t n = *fail_count;
+	uint64_t slots = 1024; // sized to the set (load <= 1/4): a small table stays in L2 while every probe is looked up in it
+	while (slots < 4 * n && slots < max_slots)
+		slots <<= 1;
+	ctl[0] = slots - 1;
+	ctl[1] = (n == 0 ? (uint64_t)GATE_NONE : n > fail_cap ? (uint64_t)GATE_REDO : (uint64_t)GATE_RESOLVE) | (n << 32);
+}
+__global__ __launch_bounds__(256) void failset_clear_auto_kernel(unsigned long long* table, const uint64_t* ctl)
+{
+	if ((uint32_t)ctl[1] != GATE_RESOLVE)
+		return;
+	const uint64_t slots = ctl[0] + 1;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x)
+		table[i] = 0;
+}
+__global__ __launch_bounds__(256) void failset_build_auto_kernel(const uint64_t* list, unsigned long long* table,
+                                                                const uint64_t* ctl)
+{
+	if ((uint32_t)ctl[1] != GATE_RESOLVE)
+		return;
+	const uint64_t n = ctl[1] >> 32, mask = ctl[0];
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const unsigned long long key = list[i] + 1;
+		uint64_t slot = mix64(key) & mask;
+		for (;;) {
+			const unsigned long long prev = atomicCAS(&table[slot], 0ull, key);
+			if (prev == 0ull || prev == key)
+				break;
+			slot = (slot + 1) & mask;
+		}
+	}
+}
+
+hipError_t launch_failset_auto(const uint64_t* fail_list, const unsigned long long* fail_count, uint64_t fail_cap,
+                               uint64_t* table, uint64_t max_slots, uint64_t* ctl, hipStream_t s)
+{
+	hipLaunchKernelGGL(failset_plan_kernel, dim3(1), dim3(1), 0, s, fail_count, fail_cap, max_slots, ctl);
+	hipLaunchKernelGGL(failset_clear_auto_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(table), ctl);
+	hipLaunchKernelGGL(failset_build_auto_kernel, dim3(512), dim3(256), 0, s, fail_list,
+	                   reinterpret_cast<unsigned long long*>(table), ctl);
+	return hipGetLastError();
+}
+
 // insert (test == 0) or test (test == 1) explicit GLOBAL positions (a spill list): positions outside
 // [lo, lo+len) are ignored; failed tests are appended to sd's fail list with their global position
 __global__ __launch_bounds__(256) void spill_kernel(uint32_t* words, const uint64_t* pos, uint64_t n, uint64_t lo,

@@ -28,6 +28,8 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	__shared__ SeqShared sh;
 
+	if (a.gate && (uint32_t)a.gate[1] != a.gate_mode)
+		return; // a step of the partitioned query that the device decided against (internal.hpp: SeqArgs::gate)
 	const uint32_t tid = threadIdx.x;
 	const uint32_t k = a.hp.k;
 	const uint32_t h = a.hp.h;
@@ -133,17 +135,18 @@ __global__ __launch_bounds__(kThreads) void seq_kernel(const SeqArgs a)
 				// (key = position + 1, 0 = empty, linear probing), a.bucket_cap its index mask
 				if (ok) {
 					const unsigned long long* table = reinterpret_cast<const unsigned long long*>(a.buckets);
+					const uint64_t tmask = a.gate ? a.gate[0] : a.bucket_cap;
 					uint32_t all = 1;
 					for (uint32_t i = 0; i < h; ++i) {
 						const unsigned long long key = reduce_mod<POW2>(wh.at(i), a.mod) + 1;
-						uint64_t slot = mix64(key) & a.bucket_cap;
+						uint64_t slot = mix64(key) & tmask;
 						for (;;) {
 							const unsigned long long v = table[slot];
 							if (v == key)
 								all = 0;
 							if (v == key || v == 0ull)
 								break;
-							slot = (slot + 1) & a.bucket_cap;
+							slot = (slot + 1) & tmask;
 						}
 					}
 					hit_mask |= all << w;

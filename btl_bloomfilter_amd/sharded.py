@@ -465,6 +465,9 @@ class ShardedBloomFilter:
         batch = -(-(-(-longest // n_batches)) // unit) * unit  # equal batches: no more memory than needed
         return batch, -(-longest // batch)
 
+    # NOTE for the C ABI: ops.route (btlbf_route_seqs) must stay free of per-filter scratch -- it runs on a second
+    # stream while btlbf_apply_routed* uses the filter's scratch on the first (capi.cpp: route passes no late list,
+    # so pass A takes its plain schedule there; tests/test_sharded.py runs both streams together)
     def _routed_pass(self, reads, read_len, query, hit_bits=None, counts=None):
         """One insert / query pass over this rank's reads on the routed path.  The unit of work is a JOB =
         (batch of reads, position window): route (pass A with the global geometry, the probes inside the
@@ -502,6 +505,10 @@ class ShardedBloomFilter:
             recv_cnt = [torch.empty(W * gc, dtype=torch.uint8, device=dev) for _ in range(r_slots)]
         spill = [torch.empty(self.SPILL_CAP, dtype=torch.int64, device=dev) for _ in range(n_slots)]
         spill_count = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_slots)]
+        # the host learns a job's spill count from a pinned copy made on the ROUTING stream right behind the routing
+        # (a .item() on the caller's stream would wait for the exchange and apply work queued there)
+        spill_host = [torch.zeros(1, dtype=torch.int64).pin_memory() if dev.type == "cuda" else None
+                      for _ in range(n_slots)]
         spilled = []  # explicit positions of the jobs done so far (device tensors)
         fail = torch.empty(self.FAIL_CAP, dtype=torch.int64, device=dev) if query else None
         fail_count = torch.zeros(1, dtype=torch.int64, device=dev) if query else None
@@ -541,6 +548,7 @@ class ShardedBloomFilter:
                 side.wait_event(free_ev[slot])  # the exchanges that read this block set have completed
             with torch.cuda.stream(side):
                 do_route(j, slot)
+                spill_host[slot].copy_(spill_count[slot], non_blocking=True)
                 routed_ev[slot] = torch.cuda.Event()
                 routed_ev[slot].record(side)
 
@@ -549,8 +557,10 @@ class ShardedBloomFilter:
             read a million times) is routed again into one that is large enough -- nothing of the job has
             left this rank yet"""
             if routed_ev[slot] is not None:
-                routed_ev[slot].synchronize()
-            n = int(spill_count[slot].item())
+                routed_ev[slot].synchronize()  # the job's routing (and the copy of its count): nothing else
+                n = int(spill_host[slot][0])
+            else:
+                n = int(spill_count[slot].item())
             while n > spill[slot].numel():
                 spill[slot] = torch.empty(n + n // 4 + 1024, dtype=torch.int64, device=dev)
                 do_route(j, slot, again=True)  # on the caller's stream; the blocks come out equivalent

@@ -782,6 +782,40 @@ def test_lazy_clear_is_invisible(bf, tmp_path):
     assert c2.compare(c1) == (0, 0, 0) and c1.download().max() == 255
 
 
+@pytest.mark.parametrize("kind", ["nonpow2", "shard"])
+def test_fresh_insert_spill_overflow_is_redone(bf, kind):
+    """the first batch into a cleared filter builds its segments from zero and reports what passes A / B could not
+    stage as explicit positions; MORE of those than the list holds (here: a short list, because the scratch budget is
+    below 2 GiB, and reads that put millions of probes on a few positions) and the batch is redone the ordinary way.
+    Non-power-of-two size and a shard (pass A's WINDOW variant): bodies against the direct kernels."""
+    import torch
+
+    h, k, L = 4, 31, 150
+    reads = bf.synth_reads_device(42, 0, 30000, L)
+    units = [b"A", b"C", b"AC", b"AG", b"ACG", b"AAT", b"ACGT", b"AACC"]
+    rep = torch.cat([torch.tensor(list((u * L)[:L]), dtype=torch.uint8, device=reads.device).repeat(6000) for u in units])
+    buf = torch.cat([reads, rep])
+    if kind == "nonpow2":
+        mk = lambda: bf.BloomFilter(3 * (1 << 29) + 64 * 7, h, k)  # noqa: E731
+    else:
+        mk = lambda: bf.BloomFilter.shard(1 << 32, 1, 4, h, k)  # noqa: E731
+    a = mk()
+    a.setInsertMode("direct")
+    a.insertSeqs(buf, read_len=L)
+    b = mk()
+    b.setInsertMode("partitioned", scratch_bytes=1 << 30)
+    b.setProfiling(True)
+    b.insertSeqs(buf, read_len=L)  # a new filter: the first batch is a fresh one
+    prof = b.getProfile()
+    assert prof["insert_hash"][1] >= 2  # the fresh attempt and its ordinary redo (or several batches)
+    assert a.compare(b) == (0, 0, 0) and a.getPop() == b.getPop() > 0
+    # and once more into the cleared filter, with room for the list this time
+    b.clear()
+    b.setInsertMode("partitioned")
+    b.insertSeqs(buf, read_len=L)
+    assert a.compare(b) == (0, 0, 0)
+
+
 # ---------------------------------------------------------------------------------------------
 # the SWIG module's surface (swig/BloomFilter.i): KmerBloomFilter + insertSeq from Python
 # ---------------------------------------------------------------------------------------------

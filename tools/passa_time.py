@@ -2,8 +2,9 @@
 
     BTLBF_LIB=btl_bloomfilter_amd/libbtlbf_<tag>.so [BTLBF_PART_GEOM=large|small] python tools/passa_time.py [reads]
 
-Diagnostic builds (BTLBF_BUILD_TAG / BTLBF_CXXFLAGS=-DBTLBF_EXP_NOPART|-DBTLBF_EXP_NOHASH) leave out the
-partition or the hashing; their filters are wrong on purpose, only the time of pass A means anything."""
+BTLBF_PART_OVERLAP=0 times the plain schedule instead of the overlapped one.  A diagnostic build
+(BTLBF_BUILD_TAG=nobar BTLBF_CXXFLAGS=-DBTLBF_EXP_NOBARRIER) leaves out the round barriers of the plain schedule; its
+filters are wrong on purpose, only the time of pass A means anything (profiles/r03/passA_overlap.md)."""
 import os
 import sys
 
