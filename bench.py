@@ -176,8 +176,8 @@ def kernel_bytes(slot, kmers_per_launch, filter_bytes, sweep_frac=1.0, fresh_fra
 KERNEL_NAMES = {
     "insert_direct": "seq_kernel<OP_BF_INSERT> (fused ntHash + atomicOr)",
     "query_direct": "seq_kernel<OP_BF_CONTAINS> (fused ntHash + gather)",
-    "insert_hash": "part_hash_kernel (pass A: fused ntHash + radix partition, insert)",
-    "query_hash": "part_hash_kernel<QUERY> (pass A: fused ntHash + radix partition, query)",
+    "insert_hash": "part_hash_ov_kernel (pass A: fused ntHash + radix partition, overlapped schedule, insert)",
+    "query_hash": "part_hash_ov_kernel<QUERY> (pass A: fused ntHash + radix partition, overlapped schedule, query)",
     "insert_split": "part_split_kernel (pass B, insert)",
     "query_split": "part_split_kernel<QUERY> (pass B, query)",
     "insert_apply": "part_apply_kernel (pass C: OR entries into the segment in LDS)",

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel-name fragments -> bench.py profile slots (the QUERY template argument separates the passes)
 def slot_of(name):
-    if "part_hash_kernel" in name:
+    if "part_hash_kernel" in name or "part_hash_ov_kernel" in name:  # plain / overlapped schedule of pass A
         return "query_hash" if is_query(name) else "insert_hash"
     if "part_split_kernel" in name:
         return "query_split" if is_query(name) else "insert_split"
@@ -34,7 +34,7 @@ def slot_of(name):
 
 
 def is_query(name):
-    # QUERY is the 4th template argument of part_hash_kernel<H, POW2, SPACED, QUERY, WINDOW> and the first
+    # QUERY is the 4th template argument of part_hash[_ov]_kernel<H, POW2, SPACED, QUERY, WINDOW[, SMALL]> and the first
     # of part_split_kernel<QUERY> / part_apply_kernel<QUERY, NT>
     args = name[name.find("<") + 1:name.find(">(")] if "<" in name else ""
     parts = [a.strip() for a in args.split(",")]

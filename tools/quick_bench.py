@@ -19,6 +19,9 @@ def main():
     f = m.BloomFilter(1 << lg, h, k)
     f.setInsertMode(mode)
     f.setQueryMode(sys.argv[4] if len(sys.argv) > 4 else "auto")
+    if os.environ.get("QB_SPACED"):  # BASELINE config 5: four spaced seeds x h2 = 1
+        f.setSpacedSeeds(["1110111011101110111011101110111", "1101101101101101011011011011011",
+                          "1111001111001111111001111001111", "1011101011101011101011101011101"], 1)
     hit_only = len(sys.argv) > 5 and sys.argv[5] == "hitonly"  # skip the all-miss query (profiling runs)
     reads = m.synth_reads_device(42, 0, n_reads, L)
     q = reads if hit_only else m.synth_reads_device(43, 0, n_reads, L)
