@@ -38,7 +38,7 @@ def is_query(name):
     # of part_split_kernel<QUERY> / part_apply_kernel<QUERY, NT>
     args = name[name.find("<") + 1:name.find(">(")] if "<" in name else ""
     parts = [a.strip() for a in args.split(",")]
-    q = parts[3] if "part_hash_kernel" in name and len(parts) > 3 else parts[0]
+    q = parts[3] if ("part_hash_kernel" in name or "part_hash_ov_kernel" in name) and len(parts) > 3 else parts[0]
     return q in ("true", "(bool)1", "1")
 
 
