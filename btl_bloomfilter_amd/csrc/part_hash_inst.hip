@@ -522,16 +522,18 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t b
 		const char* e = getenv("BTLBF_PART_OVERLAP");
 		return e && !strcmp(e, "0");
 	}();
-	const bool overlapped = !SMALL && out.P <= 64u * kOvOwners && !ov_off && sd.late_buf != nullptr &&
+	// (not for spaced seeds: their hashing keeps h values per window in registers, the overlapped kernel spills with
+	// them and ran 16 % slower than the plain one at BASELINE config 5)
+	const bool overlapped = !SMALL && !spaced && out.P <= 64u * kOvOwners && !ov_off && sd.late_buf != nullptr &&
 	                        sd.late_cap >= (uint32_t)(kPartThreads * kPartHalf * H);
 #define BTLBF_PLAUNCH(P, S, W)                                                                                      \
 	do {                                                                                                            \
-		if (!SMALL && overlapped) {                                                                                 \
-			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, S, Q, W>),   \
+		if (!SMALL && !S && overlapped) {                                                                           \
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, false, Q, W>), \
 			                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                \
 			if (e != hipSuccess)                                                                                    \
 				return e;                                                                                           \
-			hipLaunchKernelGGL((part_hash_ov_kernel<H, P, S, Q, W>), dim3(out.regions), dim3(NT), dyn, s, a, out,    \
+			hipLaunchKernelGGL((part_hash_ov_kernel<H, P, false, Q, W>), dim3(out.regions), dim3(NT), dyn, s, a, out, \
 			                   bin_shift, sd);                                                                      \
 			break;                                                                                                  \
 		}                                                                                                           \
