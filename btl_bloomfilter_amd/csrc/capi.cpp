@@ -9,7 +9,6 @@
 #include "host_internal.hpp"
 
 #include <algorithm>
-#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdarg>
@@ -20,7 +19,6 @@
 #include <map>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
@@ -337,36 +335,6 @@ Mailbox& mailbox()
 {
 	static thread_local Mailbox mb;
 	return mb;
-}
-
-// ---- combining small hash requests of many host threads -----------------------------------------------------
-// The drop-in ntHashIterator asks for the hashes of ONE short sequence per call, from as many host threads as the
-// caller runs (Tests/AdHoc/ParallelFilter.cpp:104-122 has one iterator per OpenMP thread).  A call is a kernel launch
-// and a stream synchronisation whatever it carries, and the runtime serialises much of that across threads.  So
-// concurrent requests with the same (k, h, device) are combined, group-commit fashion: the first thread to arrive
-// becomes the LEADER and runs its request; requests that arrive meanwhile queue up, and when the leader is done it
-// takes ALL of them as one ragged batch (one launch through its mailbox), hands out the results and, if more
-// have queued, goes on -- for a bounded number of batches, after which it appoints a waiting thread as the next
-// leader.  A thread alone pays nothing (its request is the batch).  No thread ever waits on a lock while it could work.
-struct HashReq {
-	const char* seq;
-	uint64_t len;
-	uint64_t* hashes;
-	uint64_t* valid; // bitmap words or nullptr
-	int rc = BTLBF_OK;
-	std::atomic<int> state{0}; // 0 waiting, 1 done, 2 "you are the leader now"
-};
-struct HashCombiner {
-	std::mutex mu;
-	std::vector<HashReq*> q;
-	bool busy = false;
-	unsigned k = 0, h = 0;
-	int device = -1;
-};
-HashCombiner& hash_combiner()
-{
-	static HashCombiner* c = new HashCombiner();
-	return *c;
 }
 
 uint64_t srol_n(uint64_t x, unsigned s)
@@ -2716,144 +2684,6 @@ extern "C" int btlbf_hash_kmers(unsigned kmer_size, unsigned hash_num, const cha
 	return BTLBF_OK;
 }
 
-namespace {
-
-// one ragged batch of short sequences through the calling thread's mailbox: [bases | starts | hash rows | valid bits]
-int hash_batch(const std::vector<HashReq*>& batch, const HashParams& hp, hipStream_t s)
-{
-	Mailbox& mb = mailbox();
-	const uint64_t up16 = ~(uint64_t)15;
-	uint64_t total = 0;
-	for (const HashReq* r : batch)
-		total += r->len;
-	const uint64_t o_st = (total + 16 + 15) & up16, o_h = o_st + (((batch.size() + 1) * 8 + 15) & up16),
-	               o_v = o_h + ((total * hp.h * 8 + 15) & up16);
-	uint64_t* starts = reinterpret_cast<uint64_t*>(mb.host + o_st);
-	uint64_t off = 0;
-	for (size_t i = 0; i < batch.size(); ++i) {
-		starts[i] = off;
-		memcpy(mb.host + off, batch[i]->seq, batch[i]->len);
-		off += batch[i]->len;
-	}
-	starts[batch.size()] = off;
-	SeqArgs a;
-	memset(&a, 0, sizeof a);
-	a.seq = mb.dev;
-	a.len = total;
-	a.layout.starts = reinterpret_cast<const uint64_t*>(mb.dev + o_st);
-	a.layout.n_seqs = batch.size();
-	a.hp = hp;
-	fill_mod(a.mod, 8, 0, 8);
-	a.hashes = reinterpret_cast<uint64_t*>(mb.dev + o_h);
-	a.valid_bits = mb.dev + o_v;
-	HIP_TRY(launch_seq_op(OP_HASH_ONLY, a, s));
-	HIP_TRY(hipStreamSynchronize(s));
-	const uint64_t* vb = reinterpret_cast<const uint64_t*>(mb.host + o_v);
-	off = 0;
-	for (HashReq* r : batch) {
-		memcpy(r->hashes, mb.host + o_h + off * hp.h * 8, r->len * hp.h * 8);
-		if (r->valid) { // bits [off, off + len) of the batch's bitmap -> bits [0, len) of the request's
-			const uint64_t words = (r->len + 63) / 64, sh = off & 63, w0 = off >> 6;
-			for (uint64_t w = 0; w < words; ++w) {
-				uint64_t v = vb[w0 + w] >> sh;
-				if (sh && (w0 + w + 1) * 64 < total + 64)
-					v |= vb[w0 + w + 1] << (64 - sh);
-				const uint64_t left = r->len - w * 64;
-				r->valid[w] = left >= 64 ? v : v & ((1ull << left) - 1);
-			}
-		}
-		off += r->len;
-	}
-	return BTLBF_OK;
-}
-
-// bytes of mailbox a batch of `n` sequences with `total` bases needs
-uint64_t hash_batch_bytes(uint64_t total, uint64_t n, unsigned h)
-{
-	return (total + 32) + (n + 1) * 8 + 16 + total * h * 8 + 16 + bitmap_bytes(total) + 64;
-}
-
-// returns the request's result code, or -1 when it cannot be combined right now (the caller then goes alone)
-int hash_combined(HashReq& me, const HashParams& hp, int device, hipStream_t s)
-{
-	HashCombiner& c = hash_combiner();
-	bool lead = false;
-	{
-		std::lock_guard<std::mutex> g(c.mu);
-		if (!c.busy) {
-			c.busy = true;
-			c.k = hp.k;
-			c.h = hp.h;
-			c.device = device;
-			lead = true;
-		} else if (c.k == hp.k && c.h == hp.h && c.device == device) {
-			c.q.push_back(&me);
-		} else {
-			return -1;
-		}
-	}
-	if (!lead) {
-		for (unsigned spins = 0;; ++spins) {
-			const int st = me.state.load(std::memory_order_acquire);
-			if (st == 1)
-				return me.rc == BTLBF_OK ? BTLBF_OK : fail(me.rc, "the combined hash batch this request was part of failed");
-			if (st == 2)
-				break; // appointed: my request is still to be done, together with whatever has queued
-			if (spins > 4096)
-				std::this_thread::yield();
-			else
-				__builtin_ia32_pause();
-		}
-	}
-	// leader: my own request first (with the queue, if I was appointed), then a bounded number of queued batches
-	std::vector<HashReq*> batch;
-	bool mine_pending = true;
-	int my_rc = BTLBF_OK;
-	for (int round = 0;; ++round) {
-		batch.clear();
-		uint64_t total = 0;
-		if (mine_pending) {
-			batch.push_back(&me);
-			total = me.len;
-		}
-		HashReq* heir = nullptr;
-		{
-			std::lock_guard<std::mutex> g(c.mu);
-			size_t take = 0;
-			while (take < c.q.size() && hash_batch_bytes(total + c.q[take]->len, batch.size() + 1, hp.h) <= Mailbox::kBytes) {
-				total += c.q[take]->len;
-				batch.push_back(c.q[take]);
-				++take;
-			}
-			c.q.erase(c.q.begin(), c.q.begin() + (long)take);
-			if (batch.empty()) { // nothing left to do: the next arrival leads
-				c.busy = false;
-				return my_rc;
-			}
-			if (round >= 8 && !mine_pending && !c.q.empty()) { // served long enough: one of the waiting threads takes over
-				heir = c.q.front();
-				c.q.erase(c.q.begin());
-			}
-		}
-		const int rc = hash_batch(batch, hp, s);
-		for (HashReq* r : batch) {
-			if (r == &me) {
-				my_rc = rc;
-				mine_pending = false;
-			} else {
-				r->rc = rc;
-				r->state.store(1, std::memory_order_release);
-			}
-		}
-		if (heir) {
-			heir->state.store(2, std::memory_order_release);
-			return my_rc;
-		}
-	}
-}
-
-} // namespace
-
 // -------------------------------------------------------------------------------------------------
 // hash streams only
 // -------------------------------------------------------------------------------------------------
@@ -2892,19 +2722,6 @@ extern "C" int btlbf_hash_seqs(unsigned kmer_size, unsigned hash_num, const char
 	const uint64_t up16 = ~(uint64_t)15;
 	const uint64_t o_h = (len + 16 + 15) & up16, o_v = o_h + ((len * hash_num * 8 + 15) & up16),
 	               o_end = o_v + ((bitmap_bytes(len) + 15) & up16);
-	if (mem == BTLBF_HOST && !seeds && !strand_bits && len && !layout && len <= 8192 &&
-	    hash_batch_bytes(len, 1, hash_num) <= Mailbox::kBytes / 4 && mailbox().get()) {
-		// one short sequence: combined with whatever other threads ask for at the same time (HashCombiner)
-		HashReq me;
-		me.seq = seq;
-		me.len = len;
-		me.hashes = hashes;
-		me.valid = valid_bits;
-		int rc = hash_combined(me, hp, device, s);
-		if (rc != -1)
-			return rc;
-		// (-1: a leader with other parameters is at work: this call goes alone, below)
-	}
 	if (mem == BTLBF_HOST && !seeds && !strand_bits && len && (!layout || !layout->starts) && o_end <= Mailbox::kBytes &&
 	    mailbox().get()) {
 		int rc = check_layout(layout, len);
