@@ -276,3 +276,45 @@ def test_single_gpu_256_gib_filter_2p41_bits(bf):
     prof = f.getProfile()
     assert "insert_hash" not in prof and prof["insert_direct"][1] == 1
     assert f.getPop() > direct[2]
+
+
+_PLAIN_SCHEDULE_CHILD = r"""
+import hashlib, json, sys
+import torch
+import btl_bloomfilter_amd as m
+bits, h, k, L, n = 1 << 36, 4, 31, 150, 2_000_000
+reads = torch.cat([m.synth_reads_device(42, 0, n, L), m.synth_reads_device(44, 0, 1000, L)[: 1000 * L - 77]])
+f = m.BloomFilter(bits, h, k)
+f.setInsertMode("partitioned", scratch_bytes=4 << 30)
+f.setProfiling(True)
+f.insertSeqs(reads[: n * L], read_len=L)
+f.insertSeqs(reads[n * L:])
+f.setQueryMode("partitioned")
+q = torch.cat([reads[: 100_000 * L], m.synth_reads_device(43, 0, 100_000, L)])
+hit, valid, cnt = f.containsSeqs(q, read_len=L, want_counts=True)
+print(json.dumps({"digest": list(f.digest()), "pop": f.getPop(), "counts": cnt.tolist(),
+                  "hit_sha1": hashlib.sha1(hit.cpu().numpy().tobytes() + valid.cpu().numpy().tobytes()).hexdigest(),
+                  "hash_launches": f.getProfile()["insert_hash"][1]}))
+"""
+
+
+def test_plain_and_overlapped_schedules_of_pass_a_build_the_same_filter():
+    """BTLBF_PART_OVERLAP=0 selects pass A's plain schedule for the geometries that otherwise take the overlapped one
+    (the switch is read once per process, hence two child processes): the same reads -- equal
+    length and ragged -- give the same array (digest, popcount) and the same query bitmaps under both."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, val in (("overlapped", "1"), ("plain", "0")):
+        env = dict(os.environ, BTLBF_PART_OVERLAP=val, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", _PLAIN_SCHEDULE_CHILD], env=env, cwd=root, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["plain"] == out["overlapped"]
+    assert out["plain"]["pop"] > 0 and out["plain"]["hash_launches"] >= 1
+    assert out["plain"]["counts"][0] >= 100_000 * 120
