@@ -1357,9 +1357,9 @@ struct PartPlan {
 	PartLevel lv[3];
 	uint64_t tiles_per_batch = 0;
 	uint64_t bytes_total = 0;
-	// pass A's overlapped schedule parks the entries that find their ring full in a list per workgroup and round
-	// parity (part_hash_inst.hip): [regions][2][late_cap] two-word entries behind the tail of the scratch
-	uint2* late_buf = nullptr;
+	// pass A's overlapped schedule keeps the entries that find their ring full in a late image per workgroup and
+	// round parity (part_hash_inst.hip): [regions][2][late_cap] words behind the tail of the scratch
+	uint32_t* late_buf = nullptr;
 	uint32_t late_cap = 0;
 };
 
@@ -1614,8 +1614,8 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
 	const uint64_t budget = scratch_budget(f);
 	*tail = part_tail(budget);
 	// (a caller-imposed budget below 2 GiB keeps its scratch for the entries: pass A then runs its plain schedule)
-	pl.late_cap = budget >= (2ull << 30) ? part_late_cap(f->hp.h) : 0;
-	const uint64_t late_bytes = (uint64_t)l0.regions * 2 * pl.late_cap * sizeof(uint2);
+	pl.late_cap = budget >= (2ull << 30) ? part_late_cap() : 0;
+	const uint64_t late_bytes = (uint64_t)l0.regions * 2 * pl.late_cap * sizeof(uint32_t);
 	const uint64_t extra_bytes = ((tail->bytes + 255) / 256) * 256 + late_bytes;
 	// a shard fed every rank's reads (ShardedBloomFilter's gather mode) keeps only its window's share
 	const double ppt = probes_per_tile(f, *tiling) * ((double)f->mod.shard_len / (double)f->mod.size);
@@ -1641,7 +1641,7 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
 	if (rc || !*ok)
 		return rc;
 	*extra = carve_levels(pl, static_cast<uint8_t*>(f->d_part), 0);
-	pl.late_buf = pl.late_cap ? reinterpret_cast<uint2*>(*extra + ((tail->bytes + 255) / 256) * 256) : nullptr;
+	pl.late_buf = pl.late_cap ? reinterpret_cast<uint32_t*>(*extra + ((tail->bytes + 255) / 256) * 256) : nullptr;
 	return BTLBF_OK;
 }
 

@@ -190,11 +190,13 @@ struct PartSide {
 	uint32_t fresh;                 // insert into an array known to be all zero (a pending btlbf_clear): pass C builds
 	                                // every segment from zero in LDS and writes it -- no read of the old contents,
 	                                // untouched segments are written as zeros
-	uint32_t late_cap;              // pass A's overlapped schedule: entries one workgroup may park per round ...
-	uint2* late_buf;                // ... in its two lists [workgroup][round parity][late_cap] (nullptr: plain schedule)
+	uint32_t late_cap;              // pass A's overlapped schedule: words of one late image (>= part_late_cap()) ...
+	uint32_t* late_buf;             // ... of [workgroup][round parity][late_cap]: where entries that found their ring
+	                                // full wait for the flush (nullptr: plain schedule)
 };
-// entries a workgroup of pass A can produce in one round (1024 lanes x 4 windows x h): what late_cap must cover
-static inline uint32_t part_late_cap(uint32_t h) { return 1024u * 4u * h; }
+// a late image mirrors the staging rings of a pass-A workgroup (partition_core.hpp kStageEntries): slot j of bin b's
+// row takes the (j+1)-th entry that found the ring of b full this round
+static inline uint32_t part_late_cap() { return 32768u; }
 
 // launchers (defined in the .hip files)
 PartTiling part_tiling(const HashParams& hp, uint32_t p0, const LayoutParams& lay, uint64_t len);

@@ -226,10 +226,11 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 // so Y's atomics of round 1 overlap X's hashing, Y's hashing and ALL of the tile staging overlap X's flushes, and
 // the top-of-tile staging phase (15 % of the plain schedule) is gone.  Hashing ahead overwrites the registers that
 // hold the current round's entries, and phase 3 still needs the "late" ones among them (0.8 % of the entries with 512
-// bins, but nearly every wave has one): here phase 1 PARKS the late entries in a list of the workgroup in global
-// memory (part_round_p1_park; L2 traffic) and the Y waves fetch them back before the round's second barrier and
-// work them off behind it -- no entry lives in a register across a barrier.  Same rounds, same ring protocol, same
-// output as the plain schedule (bit-identical filters: tests/test_gpu_parity.py, tools/fuzz_parity.py).
+// bins, but nearly every wave has one): here phase 1 stores a late entry in the round's LATE IMAGE, a mirror of the
+// rings in global memory (part_round_p1_late: addressed by what the atomic returned, no compaction; L2 traffic), and
+// the Y waves fetch the late entries back before the round's second barrier and write them into the rings behind it
+// -- no entry lives in a register across a barrier.  Same rounds, same ring protocol, same output as the plain
+// schedule (bit-identical filters: tests/test_gpu_parity.py, tools/fuzz_parity.py).
 static constexpr int kOvOwners = 8;
 
 template <int H, bool POW2, bool SPACED, bool QUERY, bool WINDOW>
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	constexpr int E = kPartHalf * H;
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
 	__shared__ SeqShared sh;
-	__shared__ uint32_t park_cnt[2]; // parked entries of the current even / odd round
+	__shared__ uint32_t p2_done; // owner waves that have left their late words (fl[]) of a round: kOvOwners per round
 	const uint32_t tid = threadIdx.x;
 	const uint32_t k = a.hp.k;
 	const bool isY = (tid >> 6) >= (uint32_t)kOvOwners; // uniform over a wave
@@ -256,9 +257,9 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	const PartLds pl = part_carve(dyn + tile_cap + seq_spaced_bytes(a.hp), out.P);
 	part_init<kPartThreads>(pl, out.P);
 	seq_setup_tables<NT, SPACED>(sh, a.hp, spaced_lds);
-	if (tid < 2)
-		park_cnt[tid] = 0;
-	uint2* const park0 = sd.late_buf + (uint64_t)blockIdx.x * 2 * sd.late_cap; // this workgroup's two lists
+	if (tid == 0)
+		p2_done = 0;
+	uint32_t* const late0 = sd.late_buf + (uint64_t)blockIdx.x * 2 * sd.late_cap; // this workgroup's two late images
 
 	uint32_t* words = static_cast<uint32_t*>(a.filter);
 	const uint32_t ent_mask = bin_shift >= 32 ? 0xffffffffu : (1u << bin_shift) - 1;
@@ -379,26 +380,39 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	};
 	auto hash_lo = [&]() { seq_lane_range<SPACED, kPartW, H, 0, kPartHalf>(tile, sh, a.hp, spaced_lds, li0, st, on_window); };
 	auto hash_hi = [&]() { seq_lane_range<SPACED, kPartW, H, kPartHalf, kPartW>(tile, sh, a.hp, spaced_lds, li0, st, on_window); };
-	// the Y waves' share of phase 3: the round's parked entries, fetched before the round's second barrier (their
-	// count is final since its first) and applied behind it; one entry per Y thread, the rest (rare) in a loop
-	uint2 parked{0, 0};
-	uint32_t n_parked = 0;
-	auto park_fetch = [&](uint32_t par) {
-		uint32_t yt = (uint32_t)ytid; // laundered: the entry's address is worked out here, not kept (and spilled)
+	// the Y waves' share of phase 3: the round's late entries (partition_core.hpp part_round_p1_late), fetched before
+	// the round's second barrier -- as soon as the owners of the bins have said how many there are -- and written into
+	// the rings behind it (the slots they go to are being flushed until then).  One bin per Y thread to look at, the
+	// entries themselves spread over the lanes of the wave.
+	uint32_t late_v = 0, late_dst = 0, late_n = 0;
+	auto late_fetch = [&](uint32_t par, uint32_t rounds_done) {
+		uint32_t yt = (uint32_t)ytid; // laundered: nothing derived from it is kept (and spilled) across the tile loop
 		asm volatile("" : "+v"(yt));
-		n_parked = park_cnt[par];
-		if (n_parked > sd.late_cap)
-			n_parked = sd.late_cap;
-		if (yt < n_parked)
-			parked = part_park_load(park0 + (uint64_t)par * sd.late_cap, yt);
+		// the owners write their words first thing behind the round's first barrier; this wave has hashed or staged
+		// since, so the wait is there for correctness, not for time
+		const uint32_t target = (rounds_done + 1) * (uint32_t)kOvOwners;
+		// (bounded all the same: every wave reaches the barrier below whatever happens)
+		for (uint32_t spin = 0; __hip_atomic_load(&p2_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && spin < (1u << 22); ++spin)
+			__builtin_amdgcn_s_sleep(1);
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		const uint32_t w = yt < out.P ? pl.fl[yt] : 0u;
+		uint32_t src;
+		late_n = part_late_assign(pl, yt & ~63u, w, 0, src, late_dst);
+		if ((yt & 63u) < late_n)
+			late_v = part_late_load(late0 + (uint64_t)par * sd.late_cap, src);
 	};
-	auto park_apply = [&](uint32_t par) {
+	auto late_apply = [&](uint32_t par) {
 		uint32_t yt = (uint32_t)ytid;
 		asm volatile("" : "+v"(yt));
-		if (yt < n_parked)
-			part_park_apply(pl, parked, ovf);
-		for (uint32_t i = yt + NY; i < n_parked; i += NY)
-			part_park_apply(pl, part_park_load(park0 + (uint64_t)par * sd.late_cap, i), ovf);
+		if ((yt & 63u) < late_n)
+			pl.stage[late_dst] = late_v;
+		for (uint32_t skip = 64; skip < late_n; skip += 64) { // more than 64 late entries in the wave's 64 bins: rare
+			const uint32_t w = yt < out.P ? pl.fl[yt] : 0u;
+			uint32_t src, dst;
+			part_late_assign(pl, yt & ~63u, w, skip, src, dst);
+			if ((yt & 63u) + skip < late_n)
+				pl.stage[dst] = part_late_load(late0 + (uint64_t)par * sd.late_cap, src);
+		}
 	};
 
 #ifdef BTLBF_PHASE_STAMPS
@@ -431,32 +445,30 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 				hash_hi();
 			} else if (t + 1 < t_end) {
 				// the next tile's words are requested BEFORE phase 1: behind it the compiler's wait for "no vector
-				// memory operation pending" in front of the loads would also wait for the stores that park late
-				// entries, and the X waves would find the Y waves still there when they arrive at the barrier
+				// memory operation pending" in front of the loads would also wait for the stores of late entries,
+				// and the X waves would find the Y waves still there when they arrive at the barrier
 				stage_request(t + 1);
 			}
 			OV_STAMP(9);
-			part_round_p1_park<E, WINDOW ? 1 : H>(pl, bin, val, live, &park_cnt[r], park0 + (uint64_t)r * sd.late_cap, sd.late_cap);
+			part_round_p1_late<E, WINDOW ? 1 : H>(pl, bin, val, live, late0 + (uint64_t)r * sd.late_cap, ovf);
 			OV_STAMP(0);
 			__syncthreads(); // (round 1: nobody reads this tile's image any more)
 			OV_STAMP(1);
 			// ---- segment b: the X waves flush; the Y waves hash ahead (round 0) or stage the next tile (round 1)
 			if (!isY) {
-				part_round_p2<NT, kOvOwners>(pl, out, 0, blockIdx.x, ovf);
+				part_round_p2<NT, kOvOwners>(pl, out, 0, blockIdx.x, ovf, &p2_done);
 			} else {
-				if (ytid == 0)
-					park_cnt[r ^ 1] = 0; // everybody is past the other round's phase 3; its next entries come behind this round
 				if (r == 0)
 					hash_hi(); // ahead of the X waves: this wave's entries of round 1
 				else if (t + 1 < t_end)
 					stage_convert(t + 1);
-				park_fetch(r);
+				late_fetch(r, (uint32_t)(t - t_begin) * 2 + r);
 			}
 			OV_STAMP(2);
 			__syncthreads();
 			OV_STAMP(3);
 			if (isY)
-				park_apply(r);
+				late_apply(r);
 			OV_STAMP(8);
 		}
 
@@ -525,7 +537,7 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t b
 	// (not for spaced seeds: their hashing keeps h values per window in registers, the overlapped kernel spills with
 	// them and ran 16 % slower than the plain one at BASELINE config 5)
 	const bool overlapped = !SMALL && !spaced && out.P <= 64u * kOvOwners && !ov_off && sd.late_buf != nullptr &&
-	                        sd.late_cap >= (uint32_t)(kPartThreads * kPartHalf * H);
+	                        sd.late_cap >= kStageEntries;
 #define BTLBF_PLAUNCH(P, S, W)                                                                                      \
 	do {                                                                                                            \
 		if (!SMALL && !S && overlapped) {                                                                           \

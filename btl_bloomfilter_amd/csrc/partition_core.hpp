@@ -96,7 +96,19 @@ static __device__ uint64_t g_stamp_out[32];
 	} while (0)
 #define STAMP_ARGS , uint64_t (&g_stamp)[16], uint64_t& g_last
 #define STAMP_PASS , g_stamp, g_last
+// inside part_round_p2 of the overlapped schedule (thread 0): slots 24.. of g_stamp_out
+#define P2_STAMP_DECL uint64_t p2_last__ = __builtin_readcyclecounter()
+#define P2_STAMP(i)                                                                                          \
+	do {                                                                                                     \
+		if (OWNERS && threadIdx.x == 0) {                                                                    \
+			const uint64_t t__ = __builtin_readcyclecounter();                                               \
+			atomicAdd((unsigned long long*)&g_stamp_out[24 + (i)], (unsigned long long)(t__ - p2_last__));   \
+			p2_last__ = t__;                                                                                 \
+		}                                                                                                    \
+	} while (0)
 #else
+#define P2_STAMP_DECL
+#define P2_STAMP(i)
 #define STAMP(i)
 #define STAMP_DECL
 #define STAMP_FLUSH
@@ -169,13 +181,17 @@ __device__ __forceinline__ bool part_round_p1(const PartLds& l, const uint32_t (
 }
 
 // Phase 1 for a schedule that must not keep the round's entries in registers across its barriers (pass A's
-// overlapped schedule): as part_round_p1, but the entries that found their ring full are PARKED -- two words each:
-// {bin | ring slot << 10 | distance behind the ring's end << 20, value} -- in a list of the workgroup in global
-// memory (0.8 % of the entries with 512 bins; L2 traffic, not HBM), one reservation per wave on an LDS counter.
-// part_park_drain works them off behind the round's second barrier.  The list holds a whole round (late_cap).
-template <int E, int G>
-__device__ __forceinline__ void part_round_p1_park(const PartLds& l, const uint32_t (&bin)[E], const uint32_t (&val)[E],
-                                                   const uint32_t live, uint32_t* park_cnt, uint2* park, uint32_t park_cap)
+// overlapped schedule): as part_round_p1, but an entry that finds its ring full is stored in the round's LATE IMAGE,
+// a mirror of the rings in global memory (a workgroup's own 128 KiB, L2 traffic): row of its bin, slot = how many
+// entries were beyond the ring's end ahead of it.  The address comes from what the atomic returned -- no compaction,
+// no second look at the entries (0.8 % of them are late with 512 bins, but every wave has one in every round: a
+// per-entry "is it late" pass costs as much as the atomics themselves).  A bin whose ring overflowed has its whole
+// ring flushed (part_round_p2), so every entry in the image fits afterwards: part_late_fetch / part_late_apply move
+// them into the rings around the round's second barrier.  Entries beyond even the image (a round that offers a bin
+// more than two rings) are the ones part_round_p2 counts as overflowed: `ovf` takes them here.
+template <int E, int G, class OVF>
+__device__ __forceinline__ void part_round_p1_late(const PartLds& l, const uint32_t (&bin)[E], const uint32_t (&val)[E],
+                                                   const uint32_t live, uint32_t* late, OVF&& ovf)
 {
 	const uint32_t tid = threadIdx.x;
 	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
@@ -193,7 +209,7 @@ __device__ __forceinline__ void part_round_p1_park(const PartLds& l, const uint3
 				old[e] = 0;
 		}
 	}
-	uint32_t late = 0; // bit e: entry e found its ring full
+	uint32_t over = 0; // bit e: entry e lies beyond the late image too
 	uint32_t* const dummy = &l.dummy[tid & 63];
 	const uint32_t stage_shift = l.sc_shift + 2, ring4 = ring << 2;
 #pragma unroll
@@ -201,54 +217,64 @@ __device__ __forceinline__ void part_round_p1_park(const PartLds& l, const uint3
 		if ((live >> g) & 1) {
 #pragma unroll
 			for (int e = g * G; e < (g + 1) * G; ++e) {
-				const bool fits = (old[e] & 0xffffu) < SC;
+				const uint32_t cnt = old[e] & 0xffffu;
+				const bool fits = cnt < SC;
 				const uint32_t slot4 = (old[e] >> 16) & ring4; // byte offset inside the ring
 				uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l.stage) + ((bin[e] << stage_shift) + slot4));
 				*(fits ? dst : dummy) = val[e];
-				late |= (uint32_t)!fits << e;
+				if (!fits) {
+					const uint32_t j = cnt - SC;
+					if (j < SC)
+						late[(bin[e] << l.sc_shift) + j] = val[e];
+					else
+						over |= 1u << e;
+				}
 			}
 		}
 	}
-	if (__any(late != 0)) {
-		const uint32_t n = __popc(late), incl = wave_scan_incl(n);
-		const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-		uint32_t base = 0;
-		if ((tid & 63) == 63)
-			base = atomicAdd(park_cnt, total);
-		base = __builtin_amdgcn_readlane(base, 63);
-		uint32_t j = base + incl - n;
+	if (__any(over != 0)) {
 #pragma unroll
-		for (int e = 0; e < E; ++e) {
-			if ((late >> e) & 1u) {
-				const uint32_t d = (old[e] & 0xffffu) - SC; // entries beyond the ring's end ahead of this one
-				if (j < park_cap)
-					park[j] = make_uint2(bin[e] | (((old[e] >> 18) & ring) << 10) | ((d < 2047u ? d : 2047u) << 20), val[e]);
-				++j;
-			}
-		}
+		for (int e = 0; e < E; ++e)
+			if ((over >> e) & 1u)
+				ovf(bin[e], val[e]);
 	}
 }
 
-// a parked entry (read back through L2: the list is rewritten every other round, L1 may hold an old line)
-__device__ __forceinline__ uint2 part_park_load(const uint2* park, uint32_t i)
+// What the owner of a bin leaves in fl[] for the waves that move the late entries (OWNERS > 0 in part_round_p2):
+// low half = entries of the bin in the late image, high half = ring slot of the first of them.
+__device__ __forceinline__ uint32_t part_late_word(uint32_t n_late, uint32_t slot0) { return n_late | (slot0 << 16); }
+
+// The late entries of the 64 bins [b0, b0 + 64) -- one bin per lane, `w` = the lane's fl[] word (0 for a lane without
+// a bin) -- spread evenly over the wave: lane i takes the i-th of them.  Returns the number of late entries of the
+// wave; lanes i < that get the image index `src` and the ring index `dst` (both in words) of their entry.
+// `skip`: entries taken in earlier calls (a wave with more than 64 late entries calls again).
+__device__ __forceinline__ uint32_t part_late_assign(const PartLds& l, uint32_t b0, uint32_t w, uint32_t skip, uint32_t& src,
+                                                     uint32_t& dst)
 {
-	const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(park) + i, __ATOMIC_RELAXED,
-	                                               __HIP_MEMORY_SCOPE_AGENT);
-	return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+	const uint32_t lane = threadIdx.x & 63, ring = (1u << l.sc_shift) - 1;
+	const uint32_t incl = wave_scan_incl(w & 0xffffu);
+	const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+	const uint32_t i = lane + skip;
+	// the lane q whose bin holds entry i: the first with incl[q] > i (binary search over the wave's prefix sums)
+	uint32_t q = 0;
+#pragma unroll
+	for (int step = 32; step > 0; step >>= 1) {
+		const uint32_t probe = q + step - 1;
+		const uint32_t v = __shfl(incl, (int)probe, 64);
+		q += v <= i ? step : 0;
+	}
+	q = q > 63 ? 63 : q;
+	const uint32_t wq = __shfl(w, (int)q, 64), iq = __shfl(incl, (int)q, 64);
+	const uint32_t j = i - (iq - (wq & 0xffffu)); // index inside bin b0 + q
+	src = ((b0 + q) << l.sc_shift) + j;
+	dst = ((b0 + q) << l.sc_shift) + (((wq >> 16) + j) & ring);
+	return total;
 }
 
-// phase 3 of one parked entry (as part_round_p3): into the ring space the flush freed if the entry now lies inside
-// the ring, else the overflow path
-template <class OVF>
-__device__ __forceinline__ void part_park_apply(const PartLds& l, const uint2 en, OVF&& ovf)
+// a late entry (read back through L2: the image is rewritten every other round, L1 may hold an old line)
+__device__ __forceinline__ uint32_t part_late_load(const uint32_t* late, uint32_t i)
 {
-	const uint32_t SC = 1u << l.sc_shift;
-	const uint32_t b = en.x & 1023u, slot = (en.x >> 10) & 1023u, d = en.x >> 20;
-	const uint32_t f = l.sc_shift == kChunkShift ? SC : l.fl[b];
-	if (d < f)
-		l.stage[(b << l.sc_shift) + slot] = en.y;
-	else
-		ovf(b, en.y);
+	return __hip_atomic_load(late + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Phase 2 (between the round's two barriers): the lanes that own bins flush the full chunks of their rings and
@@ -259,15 +285,17 @@ __device__ __forceinline__ void part_park_apply(const PartLds& l, const uint2 en
 // instructions, because the waves without bins skip this block outright); with FEW bins -- the 64-way split passes
 // of a multi-GPU owner -- they are spread over all waves, or one wave would flush everything (owner side of the C4
 // geometry: 0.65 -> 0.49 s per pass).  OWNERS > 0: the first OWNERS waves own all bins (P <= 64 * OWNERS) and only
-// they need to come here (pass A's overlapped schedule: the other waves hash meanwhile).
+// they need to come here (pass A's overlapped schedule: the other waves hash meanwhile); fl[] then holds
+// part_late_word() instead of the flushed count, and each owner wave adds one to *p2_done (LDS) once its words stand.
 template <int NT, int OWNERS = 0, class OVF>
 __device__ __forceinline__ void part_round_p2(const PartLds& l, const PartOut& o, uint32_t bin0, uint32_t region,
-                                              OVF&& ovf)
+                                              OVF&& ovf, uint32_t* p2_done = nullptr)
 {
 	const uint32_t tid = threadIdx.x;
 	const uint32_t P = o.P;
 	const uint32_t SC = 1u << l.sc_shift, ring = SC - 1;
 	const uint32_t lane = tid & 63;
+	P2_STAMP_DECL;
 	const uint32_t bpw = OWNERS ? (P + OWNERS - 1) / OWNERS : (P >= NT / 2 ? 64u : (P + NT / 64 - 1) / (NT / 64));
 	const uint32_t b = (tid >> 6) * bpw + lane;
 	uint32_t nfl = 0, rd0 = 0, w0 = 0;
@@ -281,13 +309,27 @@ __device__ __forceinline__ void part_round_p2(const PartLds& l, const PartOut& o
 		const uint32_t tot = occ - f;
 		const uint32_t nocc = tot < SC ? tot : SC;
 		l.pt[b] = (((w >> 16) - 4 * (tot - nocc)) << 16) | nocc;
-		l.fl[b] = f;
+		rd0 = ((w >> 18) - occ) & ring; // read position of the ring: both halves of pt grew alike
+		if (OWNERS) {
+			// the bin's late entries (part_round_p1_late): those beyond the ring's end, as far as the image holds them;
+			// the ring was full, so all of it is flushed now and entry j of the image goes to slot rd0 + j
+			const uint32_t n_late = occ > SC ? (occ - SC < SC ? occ - SC : SC) : 0u;
+			l.fl[b] = part_late_word(n_late, rd0);
+		} else {
+			l.fl[b] = f;
+		}
 		if (nfl) {
 			w0 = l.written[b];
 			l.written[b] = w0 + nfl;
-			rd0 = ((w >> 18) - occ) & ring; // read position of the ring: both halves of pt grew alike
 		}
 	}
+	if (OWNERS && p2_done) {
+		// this wave's fl[] words are written: tell the waves that fetch the late entries before the round's second barrier
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		if (lane == 0)
+			atomicAdd(p2_done, 1u);
+	}
+	P2_STAMP(0);
 	// inclusive prefix sum of nfl over the wave (DPP row shifts + row broadcasts, no LDS) -> slots
 	// in the wave's slice (64 bins * SC/kChunk items)
 	const uint32_t incl = wave_scan_incl(nfl);
@@ -305,6 +347,7 @@ __device__ __forceinline__ void part_round_p2(const PartLds& l, const PartOut& o
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	P2_STAMP(1);
 	// kChunk/4 lanes per chunk, 16 bytes per lane -> one aligned line per chunk
 	constexpr uint32_t kLanesPerChunk = kChunk / 4;
 	const uint32_t l4 = lane & (kLanesPerChunk - 1);
@@ -321,6 +364,7 @@ __device__ __forceinline__ void part_round_p2(const PartLds& l, const PartOut& o
 			ovf(fb, v.w);
 		}
 	}
+	P2_STAMP(2);
 }
 
 // Phase 3 (after the second barrier): entries that did not fit before the flush go into the freed ring space,

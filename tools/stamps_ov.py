@@ -17,11 +17,16 @@ raw.btlbf_debug_stamps(out)
 f.insertSeqs(reads, read_len=150); torch.cuda.synchronize()
 raw.btlbf_debug_stamps(out)
 v = list(out)
-names = ["phase 1 (atomics, ring writes, parking)", "  wait barrier 1", "segment b: X flush | Y hash ahead / stage next tile",
-         "  wait barrier 2", "-", "-", "-", "-", "Y: parked entries (phase 3)", "hash (round 0: all; round 1: X) | Y: stage request",
+names = ["phase 1 (atomics, ring writes, late stores)", "  wait barrier 1", "segment b: X flush | Y hash ahead / stage next tile",
+         "  wait barrier 2", "-", "-", "-", "-", "Y: late entries into the rings (phase 3)", "hash (round 0: all; round 1: X) | Y: stage request",
          "-", "-"]
 for role, off in (("X (wave 0)", 0), ("Y (wave 8)", 12)):
     tot = sum(v[off:off + 12]) or 1
     print(role)
     for i, nme in enumerate(names):
         print("  %-45s %6.2f %%" % (nme, 100.0 * v[off + i] / tot))
+
+tot = sum(v[0:12]) or 1
+print("inside the X wave's flush (part_round_p2), share of the X wave's tile loop")
+for i, nme in enumerate(["ring state, late words, signal", "prefix sum + flush items", "flush loop (LDS chunk -> 128-byte store)"]):
+    print("  %-45s %6.2f %%" % (nme, 100.0 * v[24 + i] / tot))
