@@ -2,6 +2,7 @@
 # round-3 measurement session (GPU box, repository root), in two halves so that each fits one gpurun call:
 #   tools/measure_r03.sh bench   -> contract bench, rocprofv3 kernel stats, PMC traffic (profiles/traffic.json)
 #   tools/measure_r03.sh side    -> SQ counters of pass A (C2 and the spaced-seed C5), config / C4 / loop benches
+#   tools/measure_r03.sh sq      -> SQ counters of pass A alone
 set -e
 ROOT=$(pwd); O=$ROOT/gpurun_out/r03; mkdir -p $O
 export TMPDIR=/tmp
@@ -31,6 +32,9 @@ side)
 	python3 tools/config_bench.py > $O/config_bench.json 2> $O/config_bench.err
 	python3 tools/c4_cost.py > $O/c4_cost.json 2> $O/c4_cost.err
 	python3 tests/loop_bench.py > $O/loop_bench.json 2> $O/loop_bench.err
+	;;
+sq)
+	sq_pass passA 39 20000000 partitioned partitioned hitonly
 	;;
 spaced)
 	QB_SPACED=1 sq_pass passA_spaced 37 20000000 partitioned partitioned hitonly
