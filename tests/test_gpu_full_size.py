@@ -101,6 +101,45 @@ def test_c2_partitioned_pipeline_at_bench_geometry(bf):
     assert cnt.tolist() == [n * 120, n * 120]
 
 
+def test_c2_geometry_skewed_reads_overflow_rings_late_image_and_regions(bf):
+    """The same 512 x 1024-bin geometry fed reads that hammer a few bins: long runs of one base (every window the same
+    k-mer: four positions), blocks of copies of one read, a low-complexity repeat.  Pass A's rings overflow, their late
+    image fills up and overflows too, regions run over their capacity -- all of that has to land in the array exactly as
+    the direct kernel puts it (insert) and to be answered like it (query)."""
+    import torch
+
+    bits, h, k, n = 1 << 39, 4, 31, 6_000_000
+    need_hbm(2 * (bits // 8) + (40 << 30))
+    reads = bf.synth_reads_device(42, 0, n, L).view(n, L)
+    reads[1_000_000:1_400_000] = ord("A")                                     # 400 000 reads of poly-A
+    reads[2_000_000:2_600_000] = reads[7].clone()                               # 600 000 copies of one read
+    acgt = torch.tensor(list(b"ACGT" * 38)[:L], dtype=torch.uint8, device="cuda")
+    reads[3_000_000:3_200_000] = acgt                                          # a period-4 repeat
+    reads[4_000_000:4_000_500, 75] = ord("N")
+    reads = reads.reshape(-1)
+    a, b = bf.BloomFilter(bits, h, k), bf.BloomFilter(bits, h, k)
+    a.setInsertMode("direct")
+    b.setInsertMode("partitioned", scratch_bytes=16 << 30)
+    b.setProfiling(True)
+    a.insertSeqs(reads, read_len=L)
+    b.insertSeqs(reads, read_len=L)
+    torch.cuda.synchronize()
+    prof = b.getProfile()
+    assert batches_of(prof, "insert_hash") >= 1 and "insert_direct" not in prof, prof
+    assert b.compare(a) == (0, 0, 0), "skewed reads: partitioned insert differs from the direct kernel"
+    assert a.digest() == b.digest() and a.getPop() == b.getPop() > 0
+    q = torch.cat([reads[: 1_500_000 * L], bf.synth_reads_device(43, 0, 10_000, L), reads[1_900_000 * L: 2_700_000 * L]])
+    out = {}
+    for mode in ("direct", "partitioned"):
+        b.setQueryMode(mode)
+        hit, valid, cnt = b.containsSeqs(q, read_len=L, want_valid=True, want_counts=True)
+        torch.cuda.synchronize()
+        out[mode] = (hit, valid, cnt.tolist())
+    assert out["direct"][2] == out["partitioned"][2]
+    assert bool(torch.equal(out["direct"][1], out["partitioned"][1])), "valid bitmaps differ"
+    assert bool(torch.equal(out["direct"][0], out["partitioned"][0])), "hit bitmaps differ"
+
+
 def test_c3_counting_filter_full_size(bf):
     """CountingBloomFilter<uint8_t>, 2^35 counters, k=25, h=3, threshold 2: incrementAll (saturation
     included) and contains through the partitioned pipeline against the direct kernels"""
