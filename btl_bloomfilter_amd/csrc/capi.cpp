@@ -140,6 +140,14 @@ struct FilterLock {
 		if (f)
 			f->mu.unlock();
 	}
+	// give the filter back early: a read-only call that has launched its kernel (on the caller's own stream, with
+	// the caller's own buffers) only waits from here on, and other threads' calls may as well run meanwhile
+	void release()
+	{
+		if (f)
+			f->mu.unlock();
+		f = nullptr;
+	}
 	FilterLock(const FilterLock&) = delete;
 	FilterLock& operator=(const FilterLock&) = delete;
 };
@@ -1189,7 +1197,7 @@ struct OutBuf {
 
 int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const btlbf_layout* layout,
                    uint64_t* hit_bits, uint64_t* valid_bits, uint64_t* counts, uint8_t* min_out, int mem,
-                   void* stream)
+                   void* stream, FilterLock* lk = nullptr)
 {
 	int rc = seq_precheck(f, len);
 	if (rc)
@@ -1228,6 +1236,8 @@ int run_query_like(btlbf_filter* f, int op, const char* seq, uint64_t len, const
 			a.min_out = min_out ? mb.dev + o_min : nullptr;
 			REQUIRE_MATERIALIZED(f);
 			HIP_TRY(launch_seq_op(op, a, s));
+			if (lk && op != OP_BF_INSERT_CHECK)
+				lk->release(); // a read-only call only waits from here on (its mailbox is the calling thread's own)
 			HIP_TRY(hipStreamSynchronize(s));
 			if (hit_bits)
 				memcpy(hit_bits, mb.host + o_hit, bitmap_bytes(len));
@@ -2450,7 +2460,7 @@ extern "C" int btlbf_contains_seqs(btlbf_filter* f, const char* seq, uint64_t le
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
 	return run_query_like(f, f->kind == BTLBF_BLOOM ? OP_BF_CONTAINS : OP_CBF_QUERY, seq, len, layout,
-	                      hit_bits, valid_bits, counts, nullptr, mem, stream);
+	                      hit_bits, valid_bits, counts, nullptr, mem, stream, &lk__);
 }
 
 extern "C" int btlbf_insert_and_check_seqs(btlbf_filter* f, const char* seq, uint64_t len,
@@ -2484,7 +2494,7 @@ extern "C" int btlbf_min_count_seqs(btlbf_filter* f, const char* seq, uint64_t l
 namespace {
 
 int run_hash_rows(btlbf_filter* f, int hop, const uint64_t* hashes, uint64_t n, uint8_t* out, int serial,
-                  int mem, void* stream)
+                  int mem, void* stream, FilterLock* lk = nullptr)
 {
 	if (!f)
 		return fail(BTLBF_EINVAL, "null filter");
@@ -2504,6 +2514,8 @@ int run_hash_rows(btlbf_filter* f, int hop, const uint64_t* hashes, uint64_t n, 
 		REQUIRE_MATERIALIZED(f);
 		HIP_TRY(launch_hash_op(hop, f->d_data, f->mod, f->h, f->thr, reinterpret_cast<const uint64_t*>(mb.dev), n,
 		                       out ? mb.dev + row_bytes : nullptr, serial, s));
+		if (lk && (hop == H_BF_CONTAINS || hop == H_CBF_CONTAINS || hop == H_CBF_MIN))
+			lk->release(); // the mailbox and (with BTLBF_STREAM_PER_THREAD) the stream are the calling thread's own
 		HIP_TRY(hipStreamSynchronize(s));
 		if (out)
 			memcpy(out, mb.host + row_bytes, n);
@@ -2555,7 +2567,7 @@ extern "C" int btlbf_contains_hashes(btlbf_filter* f, const uint64_t* hashes, ui
 	if (!f || !out)
 		return fail(BTLBF_EINVAL, "null argument");
 	return run_hash_rows(f, f->kind == BTLBF_BLOOM ? H_BF_CONTAINS : H_CBF_CONTAINS, hashes, n, out, 0, mem,
-	                     stream);
+	                     stream, &lk__);
 }
 
 extern "C" int btlbf_insert_and_check_hashes(btlbf_filter* f, const uint64_t* hashes, uint64_t n,

@@ -21,7 +21,10 @@
  *  - threads: every entry point that takes a filter holds the filter's internal lock for its whole duration
  *    (a filter keeps device scratch between calls), so ONE filter may be driven from many host threads -- the
  *    calls are serialised, the parallelism is inside each batch call -- and different filters run
- *    concurrently.  This is what makes the C++ shims safe for the reference's own threading pattern
+ *    concurrently.  One exception, for the reference's per-read query loops: a read-only call on a small
+ *    BTLBF_HOST buffer (btlbf_contains_hashes, btlbf_contains_seqs through the calling thread's pinned mailbox)
+ *    gives the lock back as soon as its kernel is launched and only then waits for it, so such calls from
+ *    different threads overlap (pass BTLBF_STREAM_PER_THREAD).  This is what makes the C++ shims safe for the reference's own threading pattern
  *    (OpenMP threads calling insert()/contains() on one filter, Tests/AdHoc/ParallelFilter.cpp:104-122;
  *    the reference itself relies on byte atomics, BloomFilter.hpp:177,191,206-210).  btlbf_destroy must not
  *    race with other calls on the same filter.  On one thread, btlbf_route_seqs may run on a second

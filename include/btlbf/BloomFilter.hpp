@@ -14,14 +14,18 @@
 //     appends to the stripe its id hashes to, under that stripe's mutex -- and the C ABI underneath
 //     serialises calls on one filter with an internal lock.  storeFilter / loadFilter while other
 //     threads insert is a caller race here as it is there.
-//   * contains()/insertAndCheck() per k-mer cost one GPU round trip each; use the *Seq/*Seqs batch
-//     members (or BloomFilterUtil.h's insertSeq) on the fast path.
+//   * insertAndCheck() per k-mer costs one GPU round trip; so does contains(hashes) -- unless the hashes are an
+//     ntHashIterator's (the reference's query loop `if (bloom.contains(*itr))`): then the first call answers every
+//     row the iterator holds in one round trip and the following ones are read from that answer, for as long as
+//     nothing was inserted in between (detail.hpp HashSpan / SpanCache; m_version below).  Use the *Seq/*Seqs
+//     batch members (or BloomFilterUtil.h's insertSeq) on the fast path.
 //   * not reproduced on purpose: the (expectedElemNum, fpr, ...) constructor, which in the reference
 //     deletes an uninitialised pointer (BloomFilter.hpp:83-99 vs :396-397).
 #ifndef BTLBF_BLOOMFILTER_HPP
 #define BTLBF_BLOOMFILTER_HPP
 #include "detail.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <fstream>
 #include <functional>
@@ -74,6 +78,7 @@ class BloomFilter
 			st.clear();
 		btlbf_shim::check(
 		    btlbf_load(&m_f, BTLBF_BLOOM, filterFilePath.c_str(), 0, btlbf_shim::default_device()));
+		touch();
 	}
 
 	// loadHeader(std::istream&), BloomFilter.hpp:118-166: consumes the header lines up to "[HeaderEnd]" and leaves a
@@ -99,6 +104,7 @@ class BloomFilter
 			st.clear();
 		btlbf_shim::check(btlbf_create_from_header(&m_f, BTLBF_BLOOM, text.data(), text.size(), 0,
 		                                           btlbf_shim::default_device()));
+		touch();
 	}
 	void loadBody(std::istream& file)
 	{
@@ -113,6 +119,7 @@ class BloomFilter
 			}
 			btlbf_shim::check(btlbf_upload(m_f, chunk.data(), off, n));
 		}
+		touch();
 	}
 	double getDesiredFPR() const { return btlbf_get_dfpr(m_f); }
 
@@ -120,14 +127,17 @@ class BloomFilter
 	void insert(const uint64_t precomputed[]) // BloomFilter.hpp:185-194
 	{
 		const unsigned h = getHashNum();
-		Stripe& st = my_stripe();
-		std::lock_guard<std::mutex> g(st.mu);
-		st.rows.insert(st.rows.end(), precomputed, precomputed + h);
-		// pushed under the stripe's lock: a flush() (= any reader) that finds the stripe empty must be able to
-		// rely on its rows having reached the filter, not on their being on their way in another thread
-		if (st.rows.size() >= kFlushRows * (size_t)h) {
-			push(st.rows);
-			st.rows.clear();
+		{
+			Stripe& st = my_stripe();
+			std::lock_guard<std::mutex> g(st.mu);
+			st.rows.insert(st.rows.end(), precomputed, precomputed + h);
+			// pushed under the stripe's lock: a flush() (= any reader) that finds the stripe empty must be able to
+			// rely on its rows having reached the filter, not on their being on their way in another thread
+			if (st.rows.size() >= kFlushRows * (size_t)h) {
+				push(st.rows);
+				st.rows.clear();
+			}
+			st.ver.store(st.ver.load(std::memory_order_relaxed) + 1, std::memory_order_release);
 		}
 	}
 	void insert(std::vector<uint64_t> const& precomputed) // BloomFilter.hpp:171-180 (.at() range check)
@@ -142,6 +152,7 @@ class BloomFilter
 		uint8_t out = 0;
 		btlbf_shim::check(btlbf_insert_and_check_hashes(m_f, precomputed, 1, &out, BTLBF_ORDER_SERIAL,
 		                                                BTLBF_HOST, nullptr));
+		touch();
 		return out != 0;
 	}
 	bool insertAndCheck(std::vector<uint64_t> const& precomputed) // BloomFilter.hpp:220-232
@@ -152,9 +163,11 @@ class BloomFilter
 
 	bool contains(const uint64_t precomputed[]) const // BloomFilter.hpp:252-262
 	{
+		if (const uint8_t* hit = lookahead(precomputed))
+			return *hit != 0;
 		flush();
 		uint8_t out = 0;
-		btlbf_shim::check(btlbf_contains_hashes(m_f, precomputed, 1, &out, BTLBF_HOST, nullptr));
+		btlbf_shim::check(btlbf_contains_hashes(m_f, precomputed, 1, &out, BTLBF_HOST, BTLBF_STREAM_PER_THREAD));
 		return out != 0;
 	}
 	bool contains(std::vector<uint64_t> const& precomputed) const // BloomFilter.hpp:237-247
@@ -169,6 +182,7 @@ class BloomFilter
 	{
 		flush();
 		btlbf_shim::check(btlbf_insert_hashes(m_f, rows, n, 0, BTLBF_ORDER_PARALLEL, BTLBF_HOST, nullptr));
+		touch();
 	}
 	std::vector<uint8_t> containsBatch(const uint64_t* rows, size_t n) const
 	{
@@ -186,14 +200,17 @@ class BloomFilter
 	{
 		if (len < getKmerSize())
 			return; // no k-mer (ntHashIterator.hpp:61-64)
-		Stripe& st = my_stripe();
-		std::lock_guard<std::mutex> g(st.mu);
-		st.starts.push_back(st.seqs.size());
-		st.seqs.append(seq, len);
-		if (st.seqs.size() >= kFlushBases) {
-			push_seqs(st);
-			st.seqs.clear();
-			st.starts.clear();
+		{
+			Stripe& st = my_stripe();
+			std::lock_guard<std::mutex> g(st.mu);
+			st.starts.push_back(st.seqs.size());
+			st.seqs.append(seq, len);
+			if (st.seqs.size() >= kFlushBases) {
+				push_seqs(st);
+				st.seqs.clear();
+				st.starts.clear();
+			}
+			st.ver.store(st.ver.load(std::memory_order_relaxed) + 1, std::memory_order_release);
 		}
 	}
 	// many sequences in one call (a batch of reads): result as if insertSeq were called on each
@@ -212,6 +229,7 @@ class BloomFilter
 		lay.n_seqs = 0;
 		lay.read_len = readLen;
 		btlbf_shim::check(btlbf_insert_seqs(m_f, reads, len, &lay, 0, BTLBF_ORDER_PARALLEL, BTLBF_HOST, nullptr));
+		touch();
 	}
 	// how many k-mers of `seq` (of the reads) contains() finds; *clean (optional) = the k-mers there are
 	uint64_t countSeq(const std::string& seq, uint64_t* clean = nullptr) const
@@ -219,7 +237,7 @@ class BloomFilter
 		flush();
 		uint64_t counts[2] = {0, 0};
 		btlbf_shim::check(btlbf_contains_seqs(m_f, seq.data(), seq.size(), nullptr, nullptr, nullptr, counts, BTLBF_HOST,
-		                                      nullptr));
+		                                      BTLBF_STREAM_PER_THREAD));
 		if (clean)
 			*clean = counts[0];
 		return counts[1];
@@ -246,6 +264,7 @@ class BloomFilter
 		btlbf_fastx_stats st;
 		btlbf_shim::check(btlbf_insert_fastx(m_f, path.c_str(), perLine ? BTLBF_FASTX_LINES : BTLBF_FASTX_RECORDS,
 		                                     batchBytes, &st));
+		touch();
 		return st;
 	}
 	// st.n_windows clean k-mers of the file, st.n_hits of them in the filter
@@ -264,7 +283,7 @@ class BloomFilter
 		const size_t nw = (seq.size() + 63) / 64;
 		std::vector<uint64_t> hb(nw ? nw : 1), vb(nw ? nw : 1);
 		btlbf_shim::check(btlbf_contains_seqs(m_f, seq.data(), seq.size(), nullptr, hb.data(), vb.data(),
-		                                      nullptr, BTLBF_HOST, nullptr));
+		                                      nullptr, BTLBF_HOST, BTLBF_STREAM_PER_THREAD));
 		result.assign(seq.size(), false);
 		valid.assign(seq.size(), false);
 		for (size_t p = 0; p < seq.size(); ++p) {
@@ -342,9 +361,11 @@ class BloomFilter
 	void setnEntry(uint64_t value) { btlbf_set_n_entry(m_f, value); }
 	void settEntry(uint64_t value) { btlbf_set_t_entry(m_f, value); }
 
-	// the C-ABI handle, for callers that want the raw batch entry points
+	// the C-ABI handle, for callers that want the raw batch entry points (what they do with it is not seen here:
+	// contains() stops trusting its look-ahead answers from now on)
 	btlbf_filter* handle() const
 	{
+		m_external.store(true, std::memory_order_release);
 		flush();
 		return m_f;
 	}
@@ -355,6 +376,7 @@ class BloomFilter
 
 	struct Stripe {
 		std::mutex mu;
+		std::atomic<uint64_t> ver{ 0 }; // bumped (under mu) with every row queued here: see version()
 		std::vector<uint64_t> rows;   // hash rows, m_hashNum each
 		std::string seqs;             // whole sequences, back to back ...
 		std::vector<uint64_t> starts; // ... and where each begins (btlbf_layout::starts without its end sentinel)
@@ -367,6 +389,44 @@ class BloomFilter
 			kmers.clear();
 		}
 	};
+	// A mutation has been queued or applied: look-ahead answers taken before this moment are void.  The version is
+	// bumped AFTER the rows are in a queue (or in the filter) and before the mutating member returns: whoever starts
+	// a contains() after that return finds a new version, refreshes its answers and flush() hands it the rows.
+	// The per-k-mer inserts count on their own stripe (one shared counter bounced between the cores cost the
+	// 16-thread insert loop two thirds of its rate); everything else counts here.
+	void touch() const { m_version.fetch_add(1, std::memory_order_acq_rel); }
+	uint64_t version() const
+	{
+		uint64_t v = m_version.load(std::memory_order_acquire);
+		for (const auto& st : m_stripes)
+			v += st.ver.load(std::memory_order_acquire);
+		return v;
+	}
+	// contains(p) for p inside the rows an ntHashIterator of this thread has announced (detail.hpp): the answer for
+	// ALL its rows is fetched with one call and kept while filter and rows stay the same.  nullptr = not applicable.
+	const uint8_t* lookahead(const uint64_t* p) const
+	{
+		const btlbf_shim::HashSpan& sp = btlbf_shim::tls_span();
+		if (!sp.base || !sp.alive || m_external.load(std::memory_order_acquire))
+			return nullptr;
+		const uintptr_t a = reinterpret_cast<uintptr_t>(p), b = reinterpret_cast<uintptr_t>(sp.base);
+		const size_t row_bytes = (size_t)sp.stride * sizeof(uint64_t);
+		if (a < b || a >= b + sp.rows * row_bytes || (a - b) % row_bytes)
+			return nullptr;
+		if (!sp.alive->load(std::memory_order_acquire) || sp.stride != getHashNum())
+			return nullptr;
+		btlbf_shim::SpanCache& c = btlbf_shim::tls_cache();
+		const uint64_t v = version();
+		if (c.filter != this || c.span_id != sp.id || c.version != v) {
+			flush();
+			c.hit.resize(sp.rows);
+			btlbf_shim::check(btlbf_contains_hashes(m_f, sp.base, sp.rows, c.hit.data(), BTLBF_HOST, BTLBF_STREAM_PER_THREAD));
+			c.filter = this;
+			c.span_id = sp.id;
+			c.version = v; // (read before the flush: a mutation that raced with this call voids the answers again)
+		}
+		return &c.hit[(a - b) / row_bytes];
+	}
 	Stripe& my_stripe() const
 	{
 		return m_stripes[std::hash<std::thread::id>()(std::this_thread::get_id()) % kStripes];
@@ -412,6 +472,10 @@ class BloomFilter
 	static constexpr size_t kStripes = 16;
 	btlbf_filter* m_f = nullptr;
 	mutable Stripe m_stripes[kStripes];
+	// (starts at a value no other filter object of this process has: an answer kept for a filter that is gone cannot
+	// be mistaken for one of a new filter at the same address)
+	mutable std::atomic<uint64_t> m_version{ btlbf_shim::next_span_id() << 32 };
+	mutable std::atomic<bool> m_external{ false };
 	double m_FPR = 0;
 };
 

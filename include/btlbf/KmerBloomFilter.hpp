@@ -38,12 +38,15 @@ class KmerBloomFilter : public BloomFilter
 	// btlbf_insert_kmers batch
 	void insert(const char* kmer) // KmerBloomFilter.hpp:63-74
 	{
-		Stripe& st = my_stripe();
-		std::lock_guard<std::mutex> g(st.mu);
-		st.kmers.append(kmer, getKmerSize());
-		if (st.kmers.size() >= kFlushKmers * (size_t)getKmerSize()) {
-			push_kmers(st.kmers);
-			st.kmers.clear();
+		{
+			Stripe& st = my_stripe();
+			std::lock_guard<std::mutex> g(st.mu);
+			st.kmers.append(kmer, getKmerSize());
+			if (st.kmers.size() >= kFlushKmers * (size_t)getKmerSize()) {
+				push_kmers(st.kmers);
+				st.kmers.clear();
+			}
+			st.ver.store(st.ver.load(std::memory_order_relaxed) + 1, std::memory_order_release);
 		}
 	}
 
@@ -52,6 +55,7 @@ class KmerBloomFilter : public BloomFilter
 	{
 		flush();
 		btlbf_shim::check(btlbf_insert_kmers(m_f, kmers, n, 0, BTLBF_ORDER_PARALLEL, BTLBF_HOST, nullptr));
+		touch();
 	}
 	std::vector<uint8_t> containsKmers(const char* kmers, size_t n) const
 	{

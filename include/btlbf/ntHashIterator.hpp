@@ -11,7 +11,9 @@
 #define BTLBF_NTHASHITERATOR_HPP
 #include "detail.hpp"
 
+#include <atomic>
 #include <limits>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -21,6 +23,33 @@ class ntHashIterator
 	ntHashIterator()
 	  : m_pos(npos())
 	{}
+	// copies hash for themselves and announce nothing; a moved-from iterator is empty
+	ntHashIterator(const ntHashIterator& o)
+	  : m_seq(o.m_seq)
+	  , m_h(o.m_h)
+	  , m_k(o.m_k)
+	  , m_pos(o.m_pos)
+	  , m_chunk0(o.m_chunk0)
+	  , m_chunk_n(o.m_chunk_n)
+	  , m_hashes(o.m_hashes)
+	  , m_valid(o.m_valid)
+	{}
+	ntHashIterator& operator=(const ntHashIterator& o)
+	{
+		if (this != &o) {
+			retire();
+			m_seq = o.m_seq;
+			m_h = o.m_h;
+			m_k = o.m_k;
+			m_pos = o.m_pos;
+			m_chunk0 = o.m_chunk0;
+			m_chunk_n = o.m_chunk_n;
+			m_hashes = o.m_hashes;
+			m_valid = o.m_valid;
+		}
+		return *this;
+	}
+	~ntHashIterator() { retire(); }
 
 	ntHashIterator(const std::string& seq, unsigned h, unsigned k, size_t pos = 0)
 	  : m_seq(seq)
@@ -61,9 +90,26 @@ class ntHashIterator
 		m_chunk_n = cnt;
 		m_hashes.resize(bytes * m_h);
 		m_valid.assign((bytes + 63) / 64, 0);
+		retire(); // (the buffer may have moved, its rows are new)
 		btlbf_shim::check(btlbf_hash_seqs(m_k, m_h, nullptr, 0, 0, m_seq.data() + start, bytes, nullptr,
 		                                  m_hashes.data(), m_valid.data(), nullptr, BTLBF_HOST,
 		                                  btlbf_shim::default_device(), BTLBF_STREAM_PER_THREAD));
+		// announce the rows to this thread's filters (detail.hpp: the look-ahead of BloomFilter::contains)
+		m_alive = std::make_shared<std::atomic<bool>>(true);
+		btlbf_shim::HashSpan& sp = btlbf_shim::tls_span();
+		sp.base = m_hashes.data();
+		sp.rows = cnt;
+		sp.stride = m_h;
+		sp.id = btlbf_shim::next_span_id();
+		sp.alive = m_alive;
+	}
+	// the announced rows are about to change or to go away
+	void retire()
+	{
+		if (m_alive) {
+			m_alive->store(false, std::memory_order_release);
+			m_alive.reset();
+		}
 	}
 
 	// advance m_pos to the first clean window at or after it (ntHashIterator.hpp:59-86)
@@ -88,6 +134,7 @@ class ntHashIterator
 	size_t m_chunk0 = 0, m_chunk_n = 0;
 	std::vector<uint64_t> m_hashes;
 	std::vector<uint64_t> m_valid;
+	std::shared_ptr<std::atomic<bool>> m_alive;
 };
 
 #endif

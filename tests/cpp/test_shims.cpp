@@ -15,7 +15,9 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unistd.h>
+#include <vector>
 
 static int g_fail = 0;
 #define CHECK(cond)                                                                    \
@@ -452,6 +454,103 @@ static void insert_seq_is_write_combined()
 	std::remove(fb.c_str());
 }
 
+// The reference's query loop `if (bloom.contains(*itr))` through the look-ahead of BloomFilter::contains
+// (include/btlbf/detail.hpp): the answers must be the ones a round trip per k-mer gives, whatever happens between the
+// calls -- inserts on this thread and on others, a second filter, copies of the iterator, iterators that are gone.
+static void contains_lookahead_is_invisible()
+{
+	const unsigned L = 150, h = 4, k = 31;
+	BloomFilter bloom(1 << 26, h, k), other(1 << 26, h, k);
+	std::vector<std::string> reads;
+	for (unsigned r = 0; r < 400; ++r)
+		reads.push_back(synth_read(5, r, L));
+	reads[3][70] = 'N';
+	for (unsigned r = 0; r < 400; r += 2)
+		insertSeq(bloom, reads[r], h, k); // even reads are in, odd ones are not
+	insertSeq(other, reads[1], h, k);
+	// 1. plain loop: equals the batch answer
+	for (unsigned r = 0; r < 8; ++r) {
+		std::vector<bool> hit, valid;
+		bloom.containsSeq(reads[r], hit, valid);
+		ntHashIterator itr(reads[r], h, k);
+		size_t seen = 0;
+		while (itr != itr.end()) {
+			CHECK(valid[itr.pos()]);
+			CHECK(bloom.contains(*itr) == hit[itr.pos()]);
+			CHECK(bloom.contains(*itr) == (r % 2 == 0)); // (no false positive in a filter this empty)
+			++seen;
+			++itr;
+		}
+		CHECK(seen == (r == 3 ? L - k + 1 - k : L - k + 1));
+	}
+	// 2. two filters asked by turns about the same rows
+	{
+		ntHashIterator itr(reads[1], h, k);
+		while (itr != itr.end()) {
+			CHECK(!bloom.contains(*itr));
+			CHECK(other.contains(*itr));
+			++itr;
+		}
+	}
+	// 3. "insert what is not there yet" (the loop of a de-duplicating loader): every answer reflects the inserts so far
+	{
+		const std::string twice = reads[5].substr(0, 100) + reads[5].substr(0, 100);
+		ntHashIterator itr(twice, h, k);
+		size_t fresh = 0, again = 0;
+		while (itr != itr.end()) {
+			if (!bloom.contains(*itr)) {
+				bloom.insert(*itr);
+				CHECK(bloom.contains(*itr));
+				++fresh;
+			} else {
+				++again;
+			}
+			++itr;
+		}
+		CHECK(fresh == 100 - k + 1 + (k - 1)); // the windows of the first copy + those across the seam
+		CHECK(again == 100 - k + 1);             // the second copy was all there
+	}
+	// 4. an insert from ANOTHER thread that has returned is seen by the next contains on this one
+	{
+		ntHashIterator itr(reads[7], h, k);
+		CHECK(!bloom.contains(*itr)); // answers for all rows of reads[7] are held now
+		std::thread t([&] { insertSeq(bloom, reads[7], h, k); });
+		t.join();
+		while (itr != itr.end()) {
+			CHECK(bloom.contains(*itr));
+			++itr;
+		}
+	}
+	// 5. copies hash for themselves; rows of an iterator that is gone are just rows
+	{
+		std::vector<uint64_t> row;
+		{
+			ntHashIterator itr(reads[9], h, k);
+			ntHashIterator cp = itr;
+			CHECK(!bloom.contains(*cp) && !bloom.contains(*itr));
+			++cp;
+			CHECK(!bloom.contains(*cp));
+			row.assign(*itr, *itr + h);
+			ntHashIterator in(reads[10], h, k);
+			CHECK(bloom.contains(*in));
+		}
+		CHECK(!bloom.contains(row.data()));
+		CHECK(!bloom.contains(row));
+	}
+	// 6. many threads, each with its own iterator, one filter
+	std::atomic<unsigned> wrong{ 0 };
+#pragma omp parallel for schedule(dynamic, 8)
+	for (int r = 20; r < 400; ++r) {
+		ntHashIterator itr(reads[(size_t)r], h, k);
+		while (itr != itr.end()) {
+			if (bloom.contains(*itr) != (r % 2 == 0))
+				++wrong;
+			++itr;
+		}
+	}
+	CHECK(wrong == 0);
+}
+
 int main(int argc, char** argv)
 {
 	bloom_basic();
@@ -463,6 +562,7 @@ int main(int argc, char** argv)
 	parallel_filter_replay(argc > 2 ? argv[2] : nullptr);
 	swig_test_pl_replay(argc > 3 ? argv[3] : nullptr);
 	insert_seq_is_write_combined();
+	contains_lookahead_is_invisible();
 	if (g_fail) {
 		std::fprintf(stderr, "%d checks failed\n", g_fail);
 		return 1;

@@ -8,7 +8,9 @@
 #include "btlbf/CountingBloomFilter.hpp"
 #include "btlbf/KmerBloomFilter.hpp"
 
+#include <atomic>
 #include <cstdio>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -42,6 +44,28 @@ int main()
 					const std::string seq(40 + i % 300, "ACGT"[i & 3]);
 					bloom.insertSeq(seq);
 					bloom.insert(seq.c_str());
+				}
+				if (i % 8192 == 4096) {
+					// the query loop's look-ahead (detail.hpp): 32 rows announced the way an ntHashIterator does,
+					// asked one by one while the other threads keep inserting; the first 17 were inserted by this
+					// thread a moment ago and must be found
+					std::vector<uint64_t> rows(32 * h);
+					for (unsigned q = 0; q < 32; ++q)
+						for (unsigned j = 0; j < h; ++j)
+							rows[q * h + j] = mix((uint64_t)t * per * h + (uint64_t)(i - 16 + q) * h + j + 1);
+					auto alive = std::make_shared<std::atomic<bool>>(true);
+					btlbf_shim::HashSpan& sp = btlbf_shim::tls_span();
+					sp.base = rows.data();
+					sp.rows = 32;
+					sp.stride = h;
+					sp.id = btlbf_shim::next_span_id();
+					sp.alive = alive;
+					for (unsigned q = 0; q < 32; ++q) {
+						const bool hit = bloom.contains(&rows[q * h]);
+						if (q <= 16)
+							miss[t] += !hit;
+					}
+					alive->store(false);
 				}
 				if (i % 64 == 0) {
 					cbf.incrementAll(row);

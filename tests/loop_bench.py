@@ -50,8 +50,9 @@ def main():
                 print(json.dumps(out["runs"][-1]), file=sys.stderr, flush=True)
         for mode in ("kmer", "seq", "batch"):
             n = n_reads if (threads > 1 or mode != "kmer") else max(n_reads // 10, 1000)
-            # per-k-mer contains() / per-read countSeq through the shims: one GPU round trip each -- a sample
-            nq = {"kmer": 500 * threads, "seq": 20000 * threads}.get(mode)
+            # contains(*itr) per k-mer (one GPU round trip per read since the look-ahead of BloomFilter::contains)
+            # and countSeq per read through the shims: a sample of the reads is enough for a rate
+            nq = {"kmer": 20000 * threads, "seq": 20000 * threads}.get(mode)
             out["runs"].append(run(SHIM, mode, n, log2_bits, threads, nq))
             print(json.dumps(out["runs"][-1]), file=sys.stderr, flush=True)
     full = [r for r in out["runs"] if r.get("reads") == n_reads]
