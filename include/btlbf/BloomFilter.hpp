@@ -474,7 +474,7 @@ class BloomFilter
 	mutable Stripe m_stripes[kStripes];
 	// (starts at a value no other filter object of this process has: an answer kept for a filter that is gone cannot
 	// be mistaken for one of a new filter at the same address)
-	mutable std::atomic<uint64_t> m_version{ btlbf_shim::next_span_id() << 32 };
+	mutable std::atomic<uint64_t> m_version{ btlbf_shim::next_span_id() << 40 };
 	mutable std::atomic<bool> m_external{ false };
 	double m_FPR = 0;
 };
