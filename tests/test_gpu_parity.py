@@ -649,6 +649,38 @@ def test_partitioned_query_equals_direct(bf, bits, miss_reads):
     assert (hit.cpu().numpy()[:nb] == out["direct"][0][:nb]).all() and (valid.cpu().numpy()[:nb] == out["direct"][1][:nb]).all()
 
 
+@pytest.mark.parametrize("L,k,n", [(100, 31, 60000), (151, 25, 40000), (50, 21, 150000), (1100, 31, 8000), (37, 31, 300000)])
+def test_split_query_other_read_lengths(bf, L, k, n):
+    """AUTO query of a buffer with a third of the reads foreign: the reads are sampled, split into a warm and a cold
+    buffer (compact_reads_kernel copies them 4 bytes per lane: L a multiple of 4 or not, reads longer than 1024
+    bytes), answered by the partitioned pipeline and the gather kernel, and the bitmaps merged back -- equal to
+    the direct kernel on the original buffer."""
+    import torch
+
+    h, bits = 4, 1 << 30
+    reads = bf.synth_reads_device(42, 0, n, L)
+    flt = bf.BloomFilter(bits, h, k)
+    flt.insertSeqs(reads, read_len=L)
+    q = reads.clone()
+    foreign = n // 3
+    idx = torch.arange(foreign, device="cuda") * 3 + 1
+    q.view(n, L)[idx] = bf.synth_reads_device(43, 0, foreign, L).view(foreign, L)
+    q[5 * L + 3] = ord("N")
+    flt.setQueryMode("direct")
+    hit_d, valid_d, cnt_d = flt.containsSeqs(q, read_len=L, want_valid=True, want_counts=True)
+    flt.setQueryMode("auto")
+    flt.setProfiling(True)
+    flt.getProfile()
+    hit_a, valid_a, cnt_a = flt.containsSeqs(q, read_len=L, want_valid=True, want_counts=True)
+    torch.cuda.synchronize()
+    prof = flt.getProfile()
+    assert "query_hash" in prof and "query_direct" in prof and "query_resolve" in prof, prof  # the split path ran
+    assert cnt_a.tolist() == cnt_d.tolist()
+    assert torch.equal(valid_a, valid_d) and torch.equal(hit_a, hit_d)
+    hit_c, _, cnt_c = flt.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    assert cnt_c.tolist() == cnt_d.tolist() and torch.equal(hit_c, hit_d)
+
+
 @pytest.mark.parametrize("L,k", [(150, 31), (100, 31), (151, 25), (50, 33), (250, 33), (152, 21)])
 def test_partitioned_many_batches_read_grid_equals_direct(bf, L, k):
     """pass A's read grid (tiles of whole reads) with a scratch cap that forces many batches: batch boundaries
