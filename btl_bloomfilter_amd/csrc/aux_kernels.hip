@@ -630,16 +630,35 @@ hipError_t launch_count_per_seq(const uint64_t* hit_bits, const uint64_t* valid_
 // one lane per sampled read (read i * stride).  A read is COLD when most of its clean samples miss (two of
 // three: a single false positive or a single SNP does not flip the call).  stride == 1: flags bit (r & 63) of
 // word r >> 6 = read r is cold.  *n_cold += cold reads among the sampled ones.
+// STAGED (stride == 1, 256 reads fit the LDS): the workgroup first copies its 256 consecutive reads into LDS with
+// coalesced 16-byte loads and the lanes take their windows from there.  Straight from global memory every 4-byte
+// load of a wave touches 64 different lines (one per read), more lines than the L1 holds between a lane's loads:
+// the kernel spent as long on fetching 62 bytes per read as on its 8 probes per read.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, uint64_t n_reads, uint32_t L, uint32_t stride,
                                                           const HashParams hp, const ModParams mod, const void* filter,
                                                           uint32_t counting, uint32_t threshold,
                                                           unsigned long long* flags, unsigned long long* n_cold)
 {
+	extern __shared__ __attribute__((aligned(16))) uint8_t staged[]; // STAGED: 256 * L + 32 bytes
 	__shared__ uint64_t tab[kNumCodes][2]; // Horner start-up seeds per base code (HashParams::init_tab)
 	__shared__ uint8_t lut[256];           // byte -> code << 4 | flags (base_entry)
 	if (threadIdx.x < kNumCodes * 2)
 		tab[threadIdx.x >> 1][threadIdx.x & 1] = hp.init_tab[threadIdx.x >> 1][threadIdx.x & 1];
 	lut[threadIdx.x] = base_entry(threadIdx.x); // 256 threads
+	uint32_t staged_off = 0; // LDS byte offset of this lane's read
+	if (STAGED) {
+		const uint64_t r_wg = (uint64_t)blockIdx.x * 256;
+		const uint64_t n_here = n_reads - r_wg < 256 ? n_reads - r_wg : 256; // (the grid covers n_reads exactly)
+		const uintptr_t a0 = reinterpret_cast<uintptr_t>(seq) + r_wg * L;
+		const uint32_t mis = (uint32_t)(a0 & 15);
+		const uint32_t pieces = (uint32_t)((mis + n_here * L + 15) / 16);
+		// (an aligned 16-byte piece that holds at least one byte of the buffer lies inside the buffer's last page)
+		const uint4* src = reinterpret_cast<const uint4*>(a0 - mis);
+		for (uint32_t p = threadIdx.x; p < pieces; p += 256)
+			reinterpret_cast<uint4*>(staged)[p] = src[p];
+		staged_off = mis + threadIdx.x * L;
+	}
 	__syncthreads();
 	const uint64_t i_s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	// stride > 1: a pseudo-random read of every block of `stride` reads, so that input with a period (every
@@ -652,14 +671,24 @@ __global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, ui
 		// one sample = full contains() of the window at `off`.  The hashing and the probing are separate steps so
 		// that the probes of the first TWO samples -- 2h independent loads -- are requested together: one memory
 		// latency for both (with one sample after the other the kernel ran at half the gather rate of the chip).
+		// four bases of the read at byte offset o (STAGED: two aligned LDS words and a byte align)
+		auto load4 = [&](uint32_t o) -> uint32_t {
+			uint32_t word;
+			if (STAGED) {
+				const uint32_t a = staged_off + o;
+				const uint32_t* l32 = reinterpret_cast<const uint32_t*>(staged) + (a >> 2);
+				word = __builtin_amdgcn_alignbyte(l32[1], l32[0], a & 3);
+			} else {
+				__builtin_memcpy(&word, rd + o, 4);
+			}
+			return word;
+		};
 		auto hash_at = [&](uint32_t off, uint64_t& b) -> bool { // -> clean window; b = canonical base hash
-			const uint8_t* w = rd + off;
 			uint64_t fh = 0, rh = 0;
 			uint32_t ok = kBaseValid;
 			uint32_t i = 0;
 			for (; i + 4 <= k; i += 4) { // four bases per (unaligned) load
-				uint32_t word;
-				__builtin_memcpy(&word, w + i, 4);
+				const uint32_t word = load4(off + i);
 				// ACGT/acgt in one step (the byte permute of seq_stage_convert), anything else through the LUT
 				const uint32_t idx = (word >> 1) & 0x03030303u;
 				uint32_t e4;
@@ -677,7 +706,7 @@ __global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, ui
 				}
 			}
 			for (; i < k; ++i) {
-				const uint32_t e = lut[w[i]];
+				const uint32_t e = lut[STAGED ? staged[staged_off + off + i] : rd[off + i]];
 				ok &= e;
 				fh = srol1(fh) ^ tab[e >> kCodeShift][0];
 				rh = sror1(rh) ^ tab[e >> kCodeShift][1];
@@ -887,8 +916,15 @@ hipError_t launch_read_sample(const uint8_t* seq, uint64_t n_reads, uint32_t L, 
 	if (n_reads == 0 || stride == 0)
 		return hipSuccess;
 	const uint64_t n_s = (n_reads + stride - 1) / stride;
-	hipLaunchKernelGGL(read_sample_kernel, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, seq, n_reads, L, stride, hp, mod,
-	                   filter, (uint32_t)counting, threshold, reinterpret_cast<unsigned long long*>(flags),
+	const size_t staged_bytes = (size_t)256 * L + 32;
+	if (stride == 1 && staged_bytes <= 40 * 1024) { // every read looked at, and 256 of them fit the LDS (L <= 159)
+		hipLaunchKernelGGL(read_sample_kernel<true>, dim3((unsigned)((n_s + 255) / 256)), dim3(256), staged_bytes, s, seq,
+		                   n_reads, L, stride, hp, mod, filter, (uint32_t)counting, threshold,
+		                   reinterpret_cast<unsigned long long*>(flags), reinterpret_cast<unsigned long long*>(n_cold));
+		return hipGetLastError();
+	}
+	hipLaunchKernelGGL(read_sample_kernel<false>, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, seq, n_reads, L, stride,
+	                   hp, mod, filter, (uint32_t)counting, threshold, reinterpret_cast<unsigned long long*>(flags),
 	                   reinterpret_cast<unsigned long long*>(n_cold));
 	return hipGetLastError();
 }
