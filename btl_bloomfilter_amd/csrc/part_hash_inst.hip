@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 				stage_request(t + 1);
 			}
 			OV_STAMP(9);
-			part_round_p1_late<E, WINDOW ? 1 : H>(pl, bin, val, live, late0 + (uint64_t)r * sd.late_cap, ovf);
+			part_round_p1_late<E, WINDOW ? 1 : H, WINDOW>(pl, bin, val, live, late0 + (uint64_t)r * sd.late_cap, ovf);
 			OV_STAMP(0);
 			__syncthreads(); // (round 1: nobody reads this tile's image any more)
 			OV_STAMP(1);

@@ -189,7 +189,7 @@ __device__ __forceinline__ bool part_round_p1(const PartLds& l, const uint32_t (
 // ring flushed (part_round_p2), so every entry in the image fits afterwards: part_late_fetch / part_late_apply move
 // them into the rings around the round's second barrier.  Entries beyond even the image (a round that offers a bin
 // more than two rings) are the ones part_round_p2 counts as overflowed: `ovf` takes them here.
-template <int E, int G, class OVF>
+template <int E, int G, bool ONE_OVF = false, class OVF>
 __device__ __forceinline__ void part_round_p1_late(const PartLds& l, const uint32_t (&bin)[E], const uint32_t (&val)[E],
                                                    const uint32_t live, uint32_t* late, OVF&& ovf)
 {
@@ -232,11 +232,31 @@ __device__ __forceinline__ void part_round_p1_late(const PartLds& l, const uint3
 			}
 		}
 	}
-	if (__any(over != 0)) {
+	// This path runs when a round offers one bin more than two rings of entries.  ONE_OVF: one copy of `ovf`, the
+	// lane's entry picked with a select chain -- sixteen inlined copies, one per entry index, cost the WINDOW / QUERY
+	// variant of pass A 32 spilled registers (gather mode's query: +11 %), while the variants without WINDOW are 3 %
+	// faster with the sixteen copies than with the chain (register allocation, not this path's run time).
+	if (!ONE_OVF) {
+		if (__any(over != 0)) {
 #pragma unroll
-		for (int e = 0; e < E; ++e)
-			if ((over >> e) & 1u)
-				ovf(bin[e], val[e]);
+			for (int e = 0; e < E; ++e)
+				if ((over >> e) & 1u)
+					ovf(bin[e], val[e]);
+		}
+		return;
+	}
+	while (__any(over != 0)) {
+		const int pick = over ? __builtin_ctz(over) : -1;
+		uint32_t b = 0, v = 0;
+#pragma unroll
+		for (int e = 0; e < E; ++e) {
+			b = pick == e ? bin[e] : b;
+			v = pick == e ? val[e] : v;
+		}
+		if (pick >= 0) {
+			ovf(b, v);
+			over &= over - 1;
+		}
 	}
 }
 
