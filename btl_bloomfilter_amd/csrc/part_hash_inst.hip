@@ -118,7 +118,11 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 		// the lane hashes its 8 consecutive windows with ONE start-up; after every 4 windows the
 		// 4*H entries collected so far go through a partition round (the rolling state stays in
 		// registers across it)
-		uint32_t bin[kPartHalf * H], val[kPartHalf * H];
+		// (more than four hashes per k-mer: rounds of two windows -- 4h entries per lane and round, with their ring
+		// slots and the rolling hash state, are more registers than a lane has: h = 8 spilled its way to 27 ms per
+		// 10^9 k-mers insert and 47 query, against 6.9 at h = 4)
+		constexpr int kWpr = H <= 4 ? kPartHalf : 2; // windows per partition round
+		uint32_t bin[kWpr * H], val[kWpr * H];
 		uint32_t vmask = 0, live = 0;
 		seq_lane_windows<SPACED, kPartW, H>(tile, sh, a.hp, spaced_lds, grid ? grid_li0 : tid * kPartW + mis, [&](int w, bool ok, const WinHash<SPACED>& wh) {
 			vmask |= (uint32_t)ok << w;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 				if (sh5 > 24 && (vmask >> (32 - sh5))) // (never beyond the bitmap: bits past a read's last window are 0)
 					atomicOr(&bm[(grid_bit >> 5) + 1], vmask >> (32 - sh5));
 			}
-			const int w4 = w % kPartHalf;
+			const int w4 = w % kWpr;
 			if (w4 == 0)
 				live = 0;
 			if (!WINDOW)
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 				bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
 				val[w4 * H + i] = (uint32_t)p & ent_mask;
 			}
-			if (w4 == kPartHalf - 1) {
+			if (w4 == kWpr - 1) {
 				STAMP(2);
 				if (SMALL) {
 					// the next tile's words (requested at the top of this tile) are pinned in their registers
@@ -164,10 +168,10 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 						for (int q = 0; q < kPartW / 4 + 1; ++q)
 							asm volatile("" : "+v"(raw.w[q]));
 					};
-					part_round_s<kPartHalf * H, WINDOW ? 1 : H>(ps, out, blockIdx.x, bin, val, live, ovf, land STAMP_PASS);
+					part_round_s<kWpr * H, WINDOW ? 1 : H>(ps, out, blockIdx.x, bin, val, live, ovf, land STAMP_PASS);
 				}
 				else
-					part_round<kPartThreads, kPartHalf * H, WINDOW ? 1 : H>(pl, out, 0, blockIdx.x, bin, val, live, ovf STAMP_PASS);
+					part_round<kPartThreads, kWpr * H, WINDOW ? 1 : H>(pl, out, 0, blockIdx.x, bin, val, live, ovf STAMP_PASS);
 			}
 		});
 		if (want_bits && grid) {
@@ -535,19 +539,25 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t b
 		return e && !strcmp(e, "0");
 	}();
 	// (not for spaced seeds: their hashing keeps h values per window in registers, the overlapped kernel spills with
-	// them and ran 16 % slower than the plain one at BASELINE config 5)
-	const bool overlapped = !SMALL && !spaced && out.P <= 64u * kOvOwners && !ov_off && sd.late_buf != nullptr &&
+	// them and ran 16 % slower than the plain one at BASELINE config 5; and not for more than four hashes per k-mer:
+	// a round's 4h entries per lane no longer fit the registers beside the hash state -- h = 5: 34.0 / 41.6 ms insert /
+	// query per 3.6x10^9 k-mers against 34.3 / 35.1 with the plain kernel, h = 6: 52.2 / 62.2 against 41.7 / 42.6,
+	// h = 8: 230 / 257 against 97 / 169; h = 3: 19.5 / 20.3 against 21.3 / 21.8)
+	constexpr bool kOvH = H <= 4;
+	const bool overlapped = !SMALL && kOvH && !spaced && out.P <= 64u * kOvOwners && !ov_off && sd.late_buf != nullptr &&
 	                        sd.late_cap >= kStageEntries;
 #define BTLBF_PLAUNCH(P, S, W)                                                                                      \
 	do {                                                                                                            \
-		if (!SMALL && !S && overlapped) {                                                                           \
-			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, false, Q, W>), \
-			                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                \
-			if (e != hipSuccess)                                                                                    \
-				return e;                                                                                           \
-			hipLaunchKernelGGL((part_hash_ov_kernel<H, P, false, Q, W>), dim3(out.regions), dim3(NT), dyn, s, a, out, \
-			                   bin_shift, sd);                                                                      \
-			break;                                                                                                  \
+		if constexpr (!SMALL && !S && kOvH) {                                                                       \
+			if (overlapped) {                                                                                       \
+				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, false, Q, W>), \
+				                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);            \
+				if (e != hipSuccess)                                                                                \
+					return e;                                                                                       \
+				hipLaunchKernelGGL((part_hash_ov_kernel<H, P, false, Q, W>), dim3(out.regions), dim3(NT), dyn, s, a, out, \
+				                   bin_shift, sd);                                                                  \
+				break;                                                                                              \
+			}                                                                                                       \
 		}                                                                                                           \
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_kernel<H, P, S, Q, W, SMALL>),    \
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                    \
