@@ -318,3 +318,50 @@ def test_plain_and_overlapped_schedules_of_pass_a_build_the_same_filter():
     assert out["plain"] == out["overlapped"]
     assert out["plain"]["pop"] > 0 and out["plain"]["hash_launches"] >= 1
     assert out["plain"]["counts"][0] >= 100_000 * 120
+
+
+def _sparse_digest(positions):
+    """btlbf_digest (include/btlbf.h) of an otherwise empty bit filter with exactly these bits set"""
+    words = {}
+    for p in positions:
+        words[p >> 6] = words.get(p >> 6, 0) | (1 << (p & 63))
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    s = x = 0
+    for i, w in words.items():
+        m = mix(i + 1) | 1
+        s = (s + w * m) & M
+        x ^= mix(w ^ m)
+    return s, x
+
+
+@pytest.mark.parametrize("bits", [(1 << 32) + 64, 48_857_600_000, 3 << 37, 5 * 10 ** 11])
+def test_positions_of_filters_beyond_2p32_bits_of_no_power_of_two_size(bf, bits):
+    """hash % size (BloomFilter.hpp:190) for sizes whose reduction takes the 32-bit-quotient path of reduce_mod
+    (device_utils.hpp: every size above 2^32 that is no power of two): 3000 rows of 64-bit hashes, inserted as rows
+    and looked up again; the array must hold exactly the bits Python's `%` says -- checked through the device-side
+    digest and the popcount, the filter being far too large to download."""
+    if _free_gib() < bits / 8 / 2 ** 30 + 4:
+        pytest.skip("not enough free HBM")
+    rng = np.random.RandomState(bits % 9973)
+    h = 3
+    hv = rng.randint(0, 2 ** 63, size=(3000, h)).astype(np.uint64) * np.uint64(2) + rng.randint(0, 2, size=(3000, h)).astype(np.uint64)
+    hv[0, 0] = np.uint64(2 ** 64 - 1)
+    hv[1, 0] = np.uint64(bits)          # -> position 0
+    hv[2, 0] = np.uint64(bits - 1)      # -> the last position
+    hv[3, 0] = np.uint64((2 ** 64 // bits) * bits - 1)
+    f = bf.BloomFilter(bits, h, 20)
+    f.insert(hv)
+    want = {int(v) % bits for v in hv.ravel().tolist()}
+    assert f.getPop() == len(want)
+    assert f.digest() == _sparse_digest(want)
+    assert f.contains(hv).all()
+    other = hv ^ np.uint64(0x5555555555555555)
+    hits = f.contains(other)
+    expect = np.array([all((int(v) % bits) in want for v in row) for row in other.tolist()])
+    assert hits.tolist() == expect.tolist()
