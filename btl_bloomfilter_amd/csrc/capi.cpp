@@ -1593,6 +1593,13 @@ int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, in
 	return BTLBF_OK;
 }
 
+// AUTO's break-even between the direct kernels and a sweep of the array, as probes per byte of the local array.
+// Measured on MI355X at 2^39 bits (tools/auto_probe.py): the direct insert costs 24.4 ms per 10^6 reads of 150 bp (21 G
+// atomics/s), the partitioned one 26.5 ms + 1.9 ms per 10^6 reads -- equal at 0.82 %; the direct query 9.3 ms per 10^6
+// reads (all hits: four gathers per k-mer), the partitioned one 17.3 ms + 1.6 per 10^6 -- equal at 1.57 %.  (Round 2's
+// rule was 2 % for both: a batch of 2x10^6 reads was inserted in 48.7 ms instead of 30.4.)
+constexpr double kAutoInsertRatio = 0.0095, kAutoQueryRatio = 0.0165;
+
 // decide between the direct (atomicOr per probe) and the partitioned insert
 // bit filters: insert; counting filters: incrementAll only (the conservative update of `insert` needs
 // the minimum over a k-mer's h counters, which live in different segments)
@@ -1607,16 +1614,16 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 	if (f->insert_mode == BTLBF_INSERT_PARTITIONED)
 		return true;
 	// auto: one sweep of the local array (read + write) must be cheaper than the random atomics it
-	// replaces: ~ 2*bytes/5e12 s against probes/21e9 s, with a 2x margin; and the batch must be big
+	// replaces: ~ 2*bytes/5.8e12 s against probes/21e9 s (kAutoInsertRatio); and the batch must be big
 	// enough to be worth five launches
 	const double probes = (double)len * f->hp.h * ((double)f->mod.shard_len / (double)f->mod.size);
-	return probes >= 0.02 * (double)f->local_bytes && probes >= 4.0e6;
+	return probes >= kAutoInsertRatio * (double)f->local_bytes && probes >= 4.0e6;
 }
 
 // plan the single-GPU pipeline for a buffer and (re)allocate the scratch;
 // *ok = false means "not applicable, use the direct kernel"
 int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan& pl, PartTiling* tiling,
-                 uint8_t** extra, bool* ok, int mode)
+                 uint8_t** extra, bool* ok, int mode, double auto_ratio)
 {
 	*ok = false;
 	if (!plan_segments(f->mod.shard_len, pl, f->kind == BTLBF_COUNTING8 ? 0 : 3))
@@ -1668,7 +1675,7 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
 	// AUTO: a batch that the scratch budget has cut small is not worth a sweep of the array either (the rule
 	// want_partitioned applies to the whole call, applied to one batch): a filter that nearly fills the HBM
 	// leaves a few GB for scratch, and the direct kernels are then the faster path
-	if (mode == BTLBF_INSERT_AUTO && tiles < tiling->n_tiles && (double)tiles * ppt < 0.02 * (double)f->local_bytes)
+	if (mode == BTLBF_INSERT_AUTO && tiles < tiling->n_tiles && (double)tiles * ppt < auto_ratio * (double)f->local_bytes)
 		return BTLBF_OK;
 	pl.tiles_per_batch = tiles;
 	int rc = ensure_scratch(f, pl.bytes_total, ok);
@@ -1693,7 +1700,7 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 	uint8_t* extra = nullptr;
 	bool ok = false;
 	PartTail tail;
-	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok, f->insert_mode);
+	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok, f->insert_mode, kAutoInsertRatio);
 	if (rc || !ok)
 		return rc;
 	const uint64_t total_tiles = tiling.n_tiles;
@@ -1788,7 +1795,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	uint8_t* extra = nullptr;
 	bool ok = false;
 	PartTail tail;
-	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok, f->query_mode);
+	int rc = part_prepare(f, base, &tail, pl, &tiling, &extra, &ok, f->query_mode, kAutoQueryRatio);
 	if (rc || !ok)
 		return rc;
 	const uint64_t total_tiles = tiling.n_tiles;
@@ -1868,7 +1875,7 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 		return BTLBF_OK;
 	}
 	const double live = (double)base.len * f->hp.h * ((double)f->mod.shard_len / (double)f->mod.size);
-	if (live < 0.02 * (double)f->local_bytes || live < 4.0e6)
+	if (live < kAutoQueryRatio * (double)f->local_bytes || live < 4.0e6)
 		return BTLBF_OK;
 	// sample 64 tiles spread over the buffer with the direct kernel
 	const uint64_t tiles = (base.len + seq_tile_windows() - 1) / seq_tile_windows();
@@ -1917,7 +1924,7 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 	const uint64_t n_reads = a.len / L;
 	const uint32_t W = L - k + 1;
 	const double live = (double)n_reads * W * f->hp.h;
-	if (live < 0.02 * (double)f->local_bytes || live < 4.0e6 || n_reads >= (1ull << 32))
+	if (live < kAutoQueryRatio * (double)f->local_bytes || live < 4.0e6 || n_reads >= (1ull << 32))
 		return BTLBF_OK; // small batches: the direct kernel (want_partitioned_query agrees)
 	const uint64_t n_fw = (n_reads + 63) / 64;
 	// temporaries are cached in the filter (grow-only, btlbf_release_scratch returns them): hipMalloc / hipFree
@@ -1960,7 +1967,7 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 	const double few_cold = 0.25 * (double)part_tail(scratch_budget(f)).fail_cap / ((double)W * f->hp.h);
 	auto warm_too_few = [&](double n_warm_reads) {
 		const double wl = n_warm_reads * W * f->hp.h;
-		return wl < 0.02 * (double)f->local_bytes || wl < 4.0e6;
+		return wl < kAutoQueryRatio * (double)f->local_bytes || wl < 4.0e6;
 	};
 	// 1. an estimate from one read in 64: all-hit and all-miss buffers -- the common cases -- are recognised at
 	//    1/64 of the cost of looking at every read

@@ -265,12 +265,12 @@ def test_single_gpu_256_gib_filter_2p41_bits(bf):
     prof = f.getProfile()
     assert prof["insert_hash"][1] >= 1 and prof["insert_split"][1] >= 2
     assert f.digest() + (f.getPop(),) == direct
-    # AUTO: the call as a whole is worth a sweep of the array (probes >= 2 % of its bytes), but with this little
-    # scratch one BATCH is not -> the direct kernel
+    # AUTO: the call as a whole is worth a sweep of the array (probes >= 0.95 % of its bytes, capi.cpp
+    # kAutoInsertRatio), but with this little scratch one BATCH is not -> the direct kernel
     del q, hit_d, hit_p
     more = bf.synth_reads_device(42, 0, 12_000_000, L)
     f.clear()
-    f.setInsertMode("auto")
+    f.setInsertMode("auto", scratch_bytes=3 << 30)
     f.getProfile()
     f.insertSeqs(more, read_len=L)
     prof = f.getProfile()
