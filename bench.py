@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--log2-bits", type=int, default=int(os.environ.get("BTLBF_BENCH_LOG2_BITS", LOG2_BITS)),
                     help="log2 of filter bits per GPU (default 39 = 64 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=2_000_000)
     return ap.parse_args()
 
@@ -94,8 +95,12 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(n_reads, log2_bits):
-    """Reference CPU path (ntHashIterator + BloomFilter insert/contains, OpenMP over reads) on bounded samples
+def cpu_baseline(n_reads, log2_bits, gpu_sample=None):
+    """gpu_sample = (digest, popcount) of the HIP library's filter after inserting the SAME n_reads reads into a
+    cleared filter of 2^log2_bits bits: compared with the digest of the filter the timed reference run builds
+    ("digest_equal": the bodies are identical, bit for bit, at the benchmark's own geometry).
+
+    Reference CPU path (ntHashIterator + BloomFilter insert/contains, OpenMP over reads) on bounded samples
     of the bench workload: all host cores and one thread, plus the C port next to the genuine
     reference on BASELINE config 1's filter (2^33 bits) so that a "port" number can be read as a reference
     number.  Falls back to the C port alone when the reference build is not on this machine."""
@@ -120,7 +125,11 @@ def cpu_baseline(n_reads, log2_bits):
                 "threads": r["threads"], "kmers": r["kmers"], "query_hits": r["hits"]}
 
     t0 = time.time()
-    allc = runner.bench_bf(n_reads, READ_LEN, K, H, bits, 42, 42, threads=cores, prefault=1)
+    want_digest = kind == "reference" and gpu_sample is not None and lg == log2_bits
+    if want_digest:
+        allc = runner.bench_bf(n_reads, READ_LEN, K, H, bits, 42, 42, threads=cores, prefault=1, skip_pop=1, digest=True)
+    else:
+        allc = runner.bench_bf(n_reads, READ_LEN, K, H, bits, 42, 42, threads=cores, prefault=1)
     n1 = max(n_reads // 16, 50_000)
     one = runner.bench_bf(n1, READ_LEN, K, H, bits, 42, 42, threads=1, prefault=0)  # pages already touched
     wall = time.time() - t0
@@ -135,6 +144,15 @@ def cpu_baseline(n_reads, log2_bits):
                                       allc["threads"], n1, wall),
         "query_hits": allc["hits"], "kmers": allc["kmers"],
     }
+    if want_digest:
+        out["digest_equal"] = tuple(allc["digest"]) == tuple(gpu_sample[0])
+        out["digest"] = {"reference": ["%016x" % v for v in allc["digest"]], "gpu": ["%016x" % v for v in gpu_sample[0]],
+                         "gpu_popcount": gpu_sample[1],
+                         "note": "btlbf_digest (include/btlbf.h) of the 2^%d-bit body after inserting the sample's %d "
+                                 "reads: the reference's m_filter on the host (oracle/ref_driver.cpp ref_bf_digest) "
+                                 "against the array in HBM" % (lg, n_reads)}
+    else:
+        out["digest_equal"] = None
     # calibration of the port against the genuine reference (same machine, same sample, C1's 2^33-bit filter)
     if kind == "reference":
         try:
@@ -147,6 +165,123 @@ def cpu_baseline(n_reads, log2_bits):
                 "ratio_port_over_reference": rate(r_port)["Mkmers_s"] / rate(r_ref)["Mkmers_s"]}
         except Exception as exc:  # never lose the baseline over its calibration
             out["port_vs_reference_c1"] = {"error": repr(exc)}
+    return out
+
+
+C5_SEEDS = ["1110111011101110111011101110111", "1101101101101101011011011011011",
+            "1111001111001111111001111001111", "1011101011101011101011101011101"]
+
+
+def side_configs(m, torch, reads, n_reads, dev):
+    """The other BASELINE configurations and the reference's everyday shapes (ragged sequences as its FASTA loader
+    produces them, Tests/AdHoc/ParallelFilter.cpp:104-122; a filter size from calcOptimalSize, BloomFilter.hpp:413-421,
+    i.e. no power of two), each run on THIS box after the timed region: one warm-up pass (scratch allocation), then
+    `reps` timed insert + query passes over the same 10^8 resident reads.  Not part of `value`."""
+    out = {}
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+
+    def run(name, make, insert, query, kmers, reps=2, note=None, extra=None):
+        try:
+            f = make()
+            f.setProfiling(True)
+            insert(f)
+            query(f)
+            torch.cuda.synchronize()
+            f.getProfile(reset=True)
+            ti = tq = 0.0
+            cnt = None
+            for _ in range(reps):
+                f.clear()
+                e = [ev() for _ in range(3)]
+                e[0].record()
+                insert(f)
+                e[1].record()
+                cnt = query(f)
+                e[2].record()
+                torch.cuda.synchronize()
+                ti += e[0].elapsed_time(e[1]) * 1e-3
+                tq += e[1].elapsed_time(e[2]) * 1e-3
+            prof = f.getProfile(reset=True)
+            c = cnt.tolist()
+            out[name] = {"insert_Mkmers_s": kmers * reps / ti / 1e6, "query_Mkmers_s": kmers * reps / tq / 1e6,
+                         "insert_ms": ti / reps * 1e3, "query_ms": tq / reps * 1e3, "kmers": c[0], "hits": c[1],
+                         "kernel_ms_per_launch": {k_: round(v[0] / v[1], 2) for k_, v in prof.items() if v[1]},
+                         "launches_per_pass": {k_: v[1] // reps for k_, v in prof.items() if v[1]}}
+            if note:
+                out[name]["note"] = note
+            if extra:
+                out[name].update(extra(f))
+            f.releaseScratch()
+            del f
+        except Exception as exc:  # a side table must never cost the bench line
+            out[name] = {"error": repr(exc)}
+        torch.cuda.empty_cache()
+
+    L = READ_LEN
+    q = lambda f, **kw: f.containsSeqs(reads, want_valid=True, want_counts=True, **kw)[2]  # noqa: E731
+    # C1: the reference's own CPU-runnable case
+    r1 = reads[: 1_000_000 * L]
+    run("C1", lambda: m.BloomFilter(1 << 33, H, K), lambda f: f.insertSeqs(r1, read_len=L),
+        lambda f: f.containsSeqs(r1, read_len=L, want_valid=True, want_counts=True)[2], 1_000_000 * (L - K + 1), reps=4,
+        note="10^6 reads, 2^33 bits, k=31, h=4", extra=lambda f: {"popcount": f.getPop()})
+    # C5: spaced seeds
+    def make_c5():
+        f = m.BloomFilter(1 << 37, 4, K)
+        f.setSpacedSeeds(C5_SEEDS, 1)
+        return f
+    run("C5", make_c5, lambda f: f.insertSeqs(reads, read_len=L), lambda f: q(f, read_len=L), n_reads * (L - K + 1),
+        note="10^8 reads, 2^37 bits, k=31, 4 spaced seeds x h2=1 (stHashIterator)")
+    # a filter of no power-of-two size
+    run("C2_3x2p37_bits", lambda: m.BloomFilter(3 << 37, H, K), lambda f: f.insertSeqs(reads, read_len=L),
+        lambda f: q(f, read_len=L), n_reads * (L - K + 1), note="C2's reads, 3*2^37 bits (48 GiB): hash % size by multiplication")
+    # ragged sequences (lengths 100..200) over the same bases
+    try:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        lens = torch.randint(100, 201, (n_reads + n_reads // 8,), device=dev, generator=g, dtype=torch.int64)
+        st = torch.cumsum(lens, 0)
+        st = st[st < n_reads * L]
+        starts = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), st,
+                            torch.tensor([n_reads * L], dtype=torch.int64, device=dev)])
+        n_seq = starts.numel() - 1
+        kmers_r = int((torch.clamp(starts[1:] - starts[:-1] - (K - 1), min=0)).sum().item())
+        del lens, st
+        run("C2_ragged", lambda: m.BloomFilter(1 << LOG2_BITS, H, K), lambda f: f.insertSeqs(reads, starts=starts),
+            lambda f: q(f, starts=starts), kmers_r,
+            note="C2's bases cut into %d sequences of 100..200 bases (btlbf_layout::starts), 2^39 bits" % n_seq)
+        del starts
+    except Exception as exc:
+        out["C2_ragged"] = {"error": repr(exc)}
+    # C3: counting filter; incrementAll + contains through the partitioned pipeline, then the reference's default
+    # insert (incrementMin, CountingBloomFilter.hpp:135-162,198-204) on the direct kernel
+    kc, hc = 25, 3
+    km3 = n_reads * (L - kc + 1)
+    run("C3_incrementAll", lambda: m.CountingBloomFilter(1 << 35, hc, kc, 2),
+        lambda f: (f.insertSeqs(reads, read_len=L, increment_all=True), f.insertSeqs(reads, read_len=L, increment_all=True)),
+        lambda f: q(f, read_len=L), 2 * km3,
+        note="10^8 reads inserted twice (incrementAll), 2^35 uint8 counters, k=25, h=3, threshold 2; insert rate counts "
+             "both insertions, query_Mkmers_s is per %d k-mers" % km3)
+    if "query_Mkmers_s" in out.get("C3_incrementAll", {}):
+        out["C3_incrementAll"]["query_Mkmers_s"] /= 2  # one query pass per timed rep, over km3 k-mers
+    try:
+        cb = m.CountingBloomFilter(1 << 35, hc, kc, 2)
+        t = []
+        for _ in range(2):
+            e0, e1 = ev(), ev()
+            e0.record()
+            cb.insertSeqs(reads, read_len=L)
+            e1.record()
+            torch.cuda.synchronize()
+            t.append(e0.elapsed_time(e1) * 1e-3)
+        _, _, c = cb.containsSeqs(reads, read_len=L, want_valid=False, want_counts=True)
+        out["C3_insert"] = {"insert_Mkmers_s": 2 * km3 / sum(t) / 1e6, "first_pass_Mkmers_s": km3 / t[0] / 1e6,
+                            "second_pass_Mkmers_s": km3 / t[1] / 1e6, "kmers": c.tolist()[0], "hits_threshold_2": c.tolist()[1],
+                            "note": "CountingBloomFilter::insert = conservative update (incrementMin), parallel mode: "
+                                    "every read set inserted twice; all k-mers must pass threshold 2 afterwards"}
+        del cb
+    except Exception as exc:
+        out["C3_insert"] = {"error": repr(exc)}
+    torch.cuda.empty_cache()
     return out
 
 
@@ -482,10 +617,31 @@ def main():
                             "ceilings, the partitioned pipeline exists to get off them (DESIGN.md section 5)"}
             except Exception as exc:
                 out["random_access_ceiling"] = {"error": repr(exc)}
-            if not args.no_cpu_baseline:
-                del reads, hit_bits
+            # the filter the CPU baseline's sample builds, built here by the HIP library: digest for "digest_equal"
+            gpu_sample = None
+            if not args.no_cpu_baseline and args.cpu_reads <= n_reads:
                 try:
-                    out["cpu_baseline"] = cpu_baseline(args.cpu_reads, args.log2_bits)
+                    do_clear()
+                    sub = reads[: args.cpu_reads * READ_LEN]
+                    _lib.check(lib.btlbf_insert_seqs(flt._h, C.c_void_p(sub.data_ptr()), sub.numel(), C.byref(lay), 0, 0,
+                                                     _lib.DEVICE, sp))
+                    torch.cuda.synchronize()
+                    gpu_sample = (flt.digest(), flt.getPop())
+                except Exception as exc:
+                    out["gpu_sample_error"] = repr(exc)
+            del hit_bits
+            flt.releaseScratch()
+            del flt
+            torch.cuda.empty_cache()
+            if not args.no_side_configs and n_reads == N_READS:
+                try:
+                    out["side_configs"] = side_configs(m, torch, reads, n_reads, dev)
+                except Exception as exc:
+                    out["side_configs"] = {"error": repr(exc)}
+            if not args.no_cpu_baseline:
+                del reads
+                try:
+                    out["cpu_baseline"] = cpu_baseline(args.cpu_reads, args.log2_bits, gpu_sample)
                 except Exception as exc:  # the baseline is a report, never a reason to lose the bench line
                     out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)

@@ -30,12 +30,17 @@ using namespace btlbf;
 // -------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
+// Every error return of this file passes here BEFORE the locals of the failing call are destroyed.  An error that
+// comes after kernels were queued would otherwise hand pooled staging buffers (DevBuf) back to the pool -- and to
+// the next call -- with that work still pending; so the device is drained first (errors are not a hot path).
 static int fail(int code, const char* fmt, ...)
 {
 	va_list ap;
 	va_start(ap, fmt);
 	vsnprintf(g_err, sizeof g_err, fmt, ap);
 	va_end(ap);
+	if (hipDeviceSynchronize() != hipSuccess)
+		(void)hipGetLastError();
 	return code;
 }
 
@@ -94,6 +99,12 @@ struct btlbf_filter {
 	// before the clear on the caller's stream cannot run after (or beside) the zeroing
 	hipEvent_t clear_ev = nullptr;
 	bool clear_ev_pending = false;
+	// ... and the zeroing itself, once some stream carries it out, is an event too: a call on ANOTHER stream (another
+	// host thread's BTLBF_STREAM_PER_THREAD, say) that finds lazy_zero already false must not look at the array
+	// while that memset is still in flight -- it waits for zero_ev first (materialize_clear)
+	hipEvent_t zero_ev = nullptr;
+	hipStream_t zero_stream = nullptr;
+	bool zero_ev_pending = false;
 	// set once btlbf_device_ptr has handed the raw pointer out: the caller may keep it, so from then on a clear
 	// zeroes eagerly on its stream (a lazily cleared array would show stale contents through that pointer)
 	bool ptr_exposed = false;
@@ -164,13 +175,37 @@ hipError_t order_after_clear(btlbf_filter* f, hipStream_t s)
 // a pending btlbf_clear takes effect now, on the stream of the operation that needs the array
 hipError_t materialize_clear(btlbf_filter* f, hipStream_t s)
 {
-	if (!f || !f->lazy_zero)
+	if (!f)
 		return hipSuccess;
+	if (!f->lazy_zero) {
+		// an earlier call zeroed the array on ITS stream: a different stream waits for that zeroing (a per-thread
+		// stream handle names a different stream in every host thread, so it always waits; waiting for an event of
+		// one's own stream costs nothing)
+		if (!f->zero_ev_pending)
+			return hipSuccess;
+		if (s == f->zero_stream && s != hipStreamPerThread)
+			return hipSuccess;
+		if (hipEventQuery(f->zero_ev) == hipSuccess) {
+			f->zero_ev_pending = false;
+			return hipSuccess;
+		}
+		(void)hipGetLastError(); // hipErrorNotReady is not an error
+		return hipStreamWaitEvent(s, f->zero_ev, 0);
+	}
 	hipError_t e = order_after_clear(f, s);
 	if (e != hipSuccess)
 		return e;
 	f->lazy_zero = false;
-	return hipMemsetAsync(f->d_data, 0, f->alloc_bytes, s);
+	e = hipMemsetAsync(f->d_data, 0, f->alloc_bytes, s);
+	if (e != hipSuccess)
+		return e;
+	if (!f->zero_ev && (e = hipEventCreateWithFlags(&f->zero_ev, hipEventDisableTiming)) != hipSuccess)
+		return e;
+	if ((e = hipEventRecord(f->zero_ev, s)) != hipSuccess)
+		return e;
+	f->zero_stream = s;
+	f->zero_ev_pending = true;
+	return hipSuccess;
 }
 
 // every launch of a kernel that reads or writes the array directly goes through this check: an entry point that
@@ -270,6 +305,25 @@ struct DevPool {
 		parked_bytes += cls;
 		return true;
 	}
+	// hand everything parked for `dev` (or for every device: dev < 0) back to the runtime: called when a hipMalloc
+	// fails -- a filter that nearly fills the HBM must not lose its scratch to parked staging buffers -- and by
+	// btlbf_release_scratch.  The caller has the device selected.
+	void drain(int dev)
+	{
+		std::vector<void*> out;
+		{
+			std::lock_guard<std::mutex> g(mu);
+			for (auto& kv : parked) {
+				if (dev >= 0 && kv.first.first != dev)
+					continue;
+				parked_bytes -= kv.first.second * kv.second.size();
+				out.insert(out.end(), kv.second.begin(), kv.second.end());
+				kv.second.clear();
+			}
+		}
+		for (void* p : out)
+			(void)hipFree(p);
+	}
 };
 DevPool& dev_pool()
 {
@@ -301,10 +355,18 @@ struct DevBuf {
 			return hipSuccess;
 		}
 		hipError_t e = hipMalloc(&p, cls);
+		if (e != hipSuccess) { // out of memory with buffers parked: give them back and try once more
+			(void)hipGetLastError();
+			dev_pool().drain(pooled_dev);
+			e = hipMalloc(&p, cls);
+		}
 		if (e == hipSuccess)
 			pooled_class = cls;
 		return e;
 	}
+	// an error return with work still queued on the stream: the buffer must not go back to the pool (its next user
+	// would share it with that work) -- freed instead, which synchronises
+	void unpool() { pooled_class = 0; }
 	template <class T>
 	T* as()
 	{
@@ -314,11 +376,19 @@ struct DevBuf {
 
 // A pinned, GPU-mapped mailbox per host thread for small HOST-mode calls: the kernel reads its input from and
 // writes its results to it directly (zero copy), so such a call is one launch and one stream synchronisation
-// instead of staging buffers and three or four copies.  Never freed (a thread's exit may come after the runtime's).
+// instead of staging buffers and three or four copies.  Freed when its thread ends.
 struct Mailbox {
 	static constexpr size_t kBytes = 1u << 20;
 	uint8_t* host = nullptr;
 	uint8_t* dev = nullptr;
+	// a thread that ends gives its pinned megabytes back (a process that starts a thread per task would otherwise pin
+	// memory without bound) -- unless the HIP runtime is already shutting down: hipHostFree then fails, harmlessly
+	~Mailbox()
+	{
+		if (host)
+			(void)hipHostFree(host);
+		host = dev = nullptr;
+	}
 	bool get()
 	{
 		if (host)
@@ -339,10 +409,15 @@ struct Mailbox {
 		return true;
 	}
 };
+// one per host thread AND device: the mapping is made under the device that is current (the filter's: every caller
+// holds a DeviceGuard) and used for filters on that device only
 Mailbox& mailbox()
 {
-	static thread_local Mailbox mb;
-	return mb;
+	static thread_local std::map<int, Mailbox> boxes;
+	int cur = 0;
+	if (hipGetDevice(&cur) != hipSuccess)
+		cur = 0;
+	return boxes[cur];
 }
 
 uint64_t srol_n(uint64_t x, unsigned s)
@@ -749,6 +824,8 @@ extern "C" int btlbf_destroy(btlbf_filter* f)
 	DeviceGuard g(f->device);
 	if (f->clear_ev)
 		(void)hipEventDestroy(f->clear_ev);
+	if (f->zero_ev)
+		(void)hipEventDestroy(f->zero_ev);
 	(void)hipFree(f->d_data);
 	(void)hipFree(f->d_scalar);
 	(void)hipFree(f->d_pos_tab);
@@ -785,6 +862,7 @@ extern "C" int btlbf_release_scratch(btlbf_filter* f)
 	(void)hipFree(f->d_flags);
 	f->d_flags = nullptr;
 	f->flags_bytes = 0;
+	dev_pool().drain(f->device); // parked staging buffers of HOST-mode calls (every user has synchronised)
 	return BTLBF_OK;
 }
 
@@ -901,6 +979,11 @@ extern "C" int btlbf_clear(btlbf_filter* f, void* stream)
 		f->lazy_zero = false;
 		f->clear_ev_pending = false;
 		HIP_TRY(hipMemsetAsync(f->d_data, 0, f->alloc_bytes, s));
+		if (!f->zero_ev)
+			HIP_TRY(hipEventCreateWithFlags(&f->zero_ev, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(f->zero_ev, s));
+		f->zero_stream = s;
+		f->zero_ev_pending = true;
 		return BTLBF_OK;
 	}
 	// lazy: zeroed by whoever touches the array next (see btlbf_filter::lazy_zero), after this point of `stream`
@@ -1514,8 +1597,14 @@ int ensure_scratch(btlbf_filter* f, uint64_t bytes, bool* ok)
 	f->d_part = nullptr;
 	f->part_bytes = 0;
 	hipError_t e = hipMalloc(&f->d_part, bytes);
+	if (e != hipSuccess) { // parked staging buffers of HOST-mode calls may be what is missing
+		(void)hipGetLastError();
+		dev_pool().drain(f->device);
+		e = hipMalloc(&f->d_part, bytes);
+	}
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
+		f->d_part = nullptr;
 		*ok = false; // no room for scratch: the caller falls back to the direct kernels
 		return BTLBF_OK;
 	}

@@ -393,10 +393,12 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 		uint32_t yt = (uint32_t)ytid; // laundered: nothing derived from it is kept (and spilled) across the tile loop
 		asm volatile("" : "+v"(yt));
 		// the owners write their words first thing behind the round's first barrier; this wave has hashed or staged
-		// since, so the wait is there for correctness, not for time
+		// since, so the wait is there for correctness, not for time.  It is NOT bounded: going on without the owners'
+		// words would drop or misplace late entries silently.  It always ends: the waves of a workgroup are co-resident,
+		// and every owner wave reaches its atomicAdd on p2_done straight behind that barrier (part_round_p2), without
+		// waiting for anything a Y wave does
 		const uint32_t target = (rounds_done + 1) * (uint32_t)kOvOwners;
-		// (bounded all the same: every wave reaches the barrier below whatever happens)
-		for (uint32_t spin = 0; __hip_atomic_load(&p2_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && spin < (1u << 22); ++spin)
+		while (__hip_atomic_load(&p2_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
 			__builtin_amdgcn_s_sleep(1);
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		const uint32_t w = yt < out.P ? pl.fl[yt] : 0u;

@@ -25,6 +25,7 @@
 #define BTLBF_BLOOMFILTER_HPP
 #include "detail.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <fstream>
@@ -402,8 +403,9 @@ class BloomFilter
 			v += st.ver.load(std::memory_order_acquire);
 		return v;
 	}
-	// contains(p) for p inside the rows an ntHashIterator of this thread has announced (detail.hpp): the answer for
-	// ALL its rows is fetched with one call and kept while filter and rows stay the same.  nullptr = not applicable.
+	// contains(p) for p inside the rows an ntHashIterator of this thread has announced (detail.hpp): the answers for
+	// a window of rows from p on are fetched with one call and kept while filter and rows stay the same.
+	// nullptr = not applicable.
 	const uint8_t* lookahead(const uint64_t* p) const
 	{
 		const btlbf_shim::HashSpan& sp = btlbf_shim::tls_span();
@@ -415,17 +417,36 @@ class BloomFilter
 			return nullptr;
 		if (!sp.alive->load(std::memory_order_acquire) || sp.stride != getHashNum())
 			return nullptr;
-		btlbf_shim::SpanCache& c = btlbf_shim::tls_cache();
+		btlbf_shim::SpanCache::Entry& c = btlbf_shim::tls_cache().find(this);
+		if (c.off_span == sp.id)
+			return nullptr; // given up on this span (see below): the one-row path
+		const size_t row = (a - b) / row_bytes;
 		const uint64_t v = version();
-		if (c.filter != this || c.span_id != sp.id || c.version != v) {
-			flush();
-			c.hit.resize(sp.rows);
-			btlbf_shim::check(btlbf_contains_hashes(m_f, sp.base, sp.rows, c.hit.data(), BTLBF_HOST, BTLBF_STREAM_PER_THREAD));
-			c.filter = this;
-			c.span_id = sp.id;
-			c.version = v; // (read before the flush: a mutation that raced with this call voids the answers again)
+		if (c.span_id == sp.id && c.version == v && row >= c.first && row - c.first < c.hit.size()) {
+			++c.served;
+			return &c.hit[row - c.first];
 		}
-		return &c.hit[(a - b) / row_bytes];
+		// refresh: a window of rows from this one on.  A loop that mutates the filter between its contains() calls
+		// (`if (!bf.contains(*itr)) bf.insert(*itr)`) voids every window after one answer: three of those in a row and
+		// the rest of the span is answered row by row, which is what such a loop costs anyway
+		if (c.span_id == sp.id && c.version != v && c.served <= 1) {
+			if (++c.streak >= btlbf_shim::SpanCache::kGiveUp) {
+				c.off_span = sp.id;
+				c.streak = 0;
+				return nullptr;
+			}
+		} else {
+			c.streak = 0;
+		}
+		flush();
+		const size_t n = std::min(btlbf_shim::SpanCache::kWindow, sp.rows - row);
+		c.hit.resize(n);
+		btlbf_shim::check(btlbf_contains_hashes(m_f, sp.base + row * sp.stride, n, c.hit.data(), BTLBF_HOST, BTLBF_STREAM_PER_THREAD));
+		c.first = row;
+		c.span_id = sp.id;
+		c.version = v; // (read before the flush: a mutation that raced with this call voids the answers again)
+		c.served = 1;
+		return &c.hit[0];
 	}
 	Stripe& my_stripe() const
 	{

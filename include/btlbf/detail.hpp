@@ -52,8 +52,9 @@ bit(const uint64_t* words, uint64_t p)
 // (Tests/AdHoc/ParallelFilter.cpp:93-101 with contains in place of insert).  One contains() is one GPU round trip; the
 // rows the iterator will hand out next are already in host memory, in the iterator's own buffer.  So an iterator
 // announces that buffer to its thread (HashSpan), and BloomFilter::contains(p) with p inside the announced buffer
-// answers ALL its rows in one call and keeps the answers (SpanCache) for as long as neither the buffer nor the filter
-// changes: one round trip per read instead of one per k-mer, invisible to the caller.
+// answers a window of its rows in one call and keeps the answers (SpanCache) for as long as neither the buffer nor the
+// filter changes: one round trip per read (per 4096 k-mers of a long sequence) instead of one per k-mer, invisible to
+// the caller.
 struct HashSpan {
 	const uint64_t* base = nullptr;           // rows[0]
 	size_t rows = 0;                          // rows of `stride` values each
@@ -73,10 +74,42 @@ next_span_id()
 	static std::atomic<uint64_t> c{ 1 };
 	return c.fetch_add(1, std::memory_order_relaxed);
 }
+// The answers one thread keeps: per FILTER (a loop that asks two filters by turns -- `a.contains(*itr) &&
+// b.contains(*itr)` -- must not throw one's answers away for the other's), for a WINDOW of at most kWindow rows ahead of
+// the row asked for (an iterator over a chromosome announces up to 2^20 rows: re-querying all of them after every
+// mutation made `if (!bf.contains(*itr)) bf.insert(*itr)` quadratic), and with a way out: a span whose answers were
+// voided three times in a row after serving one row each goes back to the one-row path for the rest of that span.
 struct SpanCache {
-	const void* filter = nullptr;
-	uint64_t version = 0, span_id = 0;
-	std::vector<uint8_t> hit; // one byte per row of the span
+	static constexpr size_t kWindow = 4096, kFilters = 4;
+	static constexpr unsigned kGiveUp = 3;
+	struct Entry {
+		const void* filter = nullptr;
+		uint64_t version = 0, span_id = 0;
+		size_t first = 0;         // row of the span that hit[0] answers
+		std::vector<uint8_t> hit; // one byte per row of the window
+		unsigned served = 0;      // rows answered since the last refresh
+		unsigned streak = 0;      // refreshes in a row that had served at most one row
+		uint64_t off_span = 0;    // the span this filter has given up on (0: none)
+		uint64_t stamp = 0;
+	};
+	Entry e[kFilters];
+	uint64_t clock = 0;
+	Entry& find(const void* filter)
+	{
+		Entry* lru = &e[0];
+		for (Entry& x : e) {
+			if (x.filter == filter) {
+				x.stamp = ++clock;
+				return x;
+			}
+			if (x.stamp < lru->stamp)
+				lru = &x;
+		}
+		*lru = Entry();
+		lru->filter = filter;
+		lru->stamp = ++clock;
+		return *lru;
+	}
 };
 inline SpanCache&
 tls_cache()

@@ -276,6 +276,16 @@ class Ref:
                                    C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.ref_bench_synth_only.restype = C.c_double
         L.ref_bench_synth_only.argtypes = [C.c_uint64, C.c_uint, C.c_uint64, C.c_int]
+        L.ref_bench_bf_digest.restype = C.c_int
+        L.ref_bench_bf_digest.argtypes = L.ref_bench_bf.argtypes + [C.POINTER(C.c_uint64)]
+        L.ref_bf_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.ref_cbf_digest.argtypes = [vp, C.c_uint, C.POINTER(C.c_uint64)]
+        L.ref_cbf_increment_all_synth.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint]
+        L.ref_cbf_count_synth.restype = C.c_uint64
+        L.ref_cbf_count_synth.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint]
+        L.ref_bf_spaced_synth.restype = C.c_uint64
+        L.ref_bf_spaced_synth.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint, C.c_uint, C.c_uint64, C.c_uint64,
+                                          C.c_uint64, C.c_uint, C.c_int]
 
     def nthash_seq(self, seq, h, k):
         s = _bytes(seq)
@@ -354,6 +364,18 @@ class Ref:
         def count_synth(self, seed, first, n, read_len):
             return int(self.L.ref_bf_count_synth(self.p, seed, first, n, read_len))
 
+        def spaced_synth(self, seeds, h2, seed, first, n, read_len, query=False):
+            """stHashIterator over synthetic reads: insert (query=False) or count of k-mers found (query=True)"""
+            arr = (C.c_char_p * len(seeds))(*[_bytes(x) for x in seeds])
+            return int(self.L.ref_bf_spaced_synth(self.p, arr, len(seeds), h2, seed, first, n, read_len, int(query)))
+
+        def digest(self):
+            """(sum, xor) of the body where it lies: the definition of btlbf_digest (include/btlbf.h)"""
+            out = (C.c_uint64 * 3)()
+            self.L.ref_bf_digest(self.p, out)
+            self.last_pop = int(out[2])  # set bits, counted in the same sweep
+            return int(out[0]), int(out[1])
+
         def insert_kmer(self, kmer):
             self.L.ref_kbf_insert_kmer(self.p, _bytes(kmer))
 
@@ -417,6 +439,19 @@ class Ref:
         def update_synth(self, seed, first, n, read_len, op):
             self.L.ref_cbf_update_synth(self.p, seed, first, n, read_len, op)
 
+        def increment_all_synth(self, seed, first, n, read_len):
+            self.L.ref_cbf_increment_all_synth(self.p, seed, first, n, read_len)
+
+        def count_synth(self, seed, first, n, read_len):
+            return int(self.L.ref_cbf_count_synth(self.p, seed, first, n, read_len))
+
+        def digest(self, thr=1):
+            """(sum, xor); self.last_counts = (non-zero counters, counters >= thr) from the same sweep"""
+            out = (C.c_uint64 * 4)()
+            self.L.ref_cbf_digest(self.p, thr, out)
+            self.last_counts = (int(out[2]), int(out[3]))
+            return int(out[0]), int(out[1])
+
         def popcount(self):
             return int(self.L.ref_cbf_popcount(self.p))
 
@@ -438,12 +473,16 @@ class Ref:
         return out
 
     def bench_bf(self, n_reads, read_len, k, h, bits, seed_ins, seed_qry, threads=0, prefault=1,
-                 skip_pop=1):
+                 skip_pop=1, digest=False):
         out = (C.c_double * 6)()
-        self.L.ref_bench_bf(n_reads, read_len, k, h, bits, seed_ins, seed_qry, threads, prefault,
-                            skip_pop, out)
-        return dict(t_insert=out[0], t_query=out[1], hits=int(out[2]), kmers=int(out[3]),
-                    threads=int(out[4]), popcount=int(out[5]))
+        dg = (C.c_uint64 * 2)()
+        self.L.ref_bench_bf_digest(n_reads, read_len, k, h, bits, seed_ins, seed_qry, threads, prefault,
+                                   skip_pop, out, dg if digest else None)
+        r = dict(t_insert=out[0], t_query=out[1], hits=int(out[2]), kmers=int(out[3]),
+                 threads=int(out[4]), popcount=int(out[5]))
+        if digest:
+            r["digest"] = (int(dg[0]), int(dg[1]))
+        return r
 
     def bench_synth_only(self, n_reads, read_len, seed, threads=0):
         return float(self.L.ref_bench_synth_only(n_reads, read_len, seed, threads))

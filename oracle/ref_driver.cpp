@@ -320,6 +320,156 @@ extern "C"
 		}
 		return hits;
 	}
+	// ---- digests of a reference filter body, where it lies (the definition of btlbf_digest, include/btlbf.h) ----
+	// With w_i the i-th little-endian 64-bit word of the body (BloomFilter.hpp:436 m_filter, written bit by bit at
+	// :185-194; CountingBloomFilter.hpp:102 m_filter, :165-183) and m_i = mix64(i + 1) | 1:
+	//   out2[0] = sum over the non-zero words of w_i * m_i (mod 2^64), out2[1] = xor over them of mix64(w_i ^ m_i).
+	// Lets a 64 GiB reference filter built on the GPU box's host be compared with the array in HBM without moving
+	// either (tests/test_gpu_ref_full_size.py, bench.py cpu_baseline "digest_equal").
+	// out3[2] = set bits (what BloomFilter::getPop, BloomFilter.hpp:316-323, returns -- counted here with OpenMP and
+	// popcount instead of its single-threaded byte table, which needs a minute for 64 GiB)
+	void ref_bf_digest(void* p, uint64_t* out3)
+	{
+		RefBF* f = static_cast<RefBF*>(p);
+		const uint8_t* b = f->bytes();
+		const int64_t nb = (int64_t)f->sizeInBytes();
+		const int64_t nw = nb / 8;
+		uint64_t sum = 0, x = 0, pop = 0;
+#pragma omp parallel for schedule(static) reduction(+ : sum, pop) reduction(^ : x)
+		for (int64_t i = 0; i < nw; ++i) {
+			uint64_t w;
+			memcpy(&w, b + 8 * i, 8);
+			if (w) {
+				const uint64_t m = mix64((uint64_t)i + 1) | 1ULL;
+				sum += w * m;
+				x ^= mix64(w ^ m);
+				pop += (uint64_t)__builtin_popcountll(w);
+			}
+		}
+		if (nb % 8) { // a body that is no whole number of words: zero-padded
+			uint64_t w = 0;
+			memcpy(&w, b + 8 * nw, (size_t)(nb % 8));
+			if (w) {
+				const uint64_t m = mix64((uint64_t)nw + 1) | 1ULL;
+				sum += w * m;
+				x ^= mix64(w ^ m);
+				pop += (uint64_t)__builtin_popcountll(w);
+			}
+		}
+		out3[0] = sum;
+		out3[1] = x;
+		out3[2] = pop;
+	}
+	// out4[2] = non-zero counters (popCount, CountingBloomFilter.hpp:217-228), out4[3] = counters >= thr
+	// (filtered_popcount, :231-242), counted with OpenMP
+	void ref_cbf_digest(void* p, unsigned thr, uint64_t* out4)
+	{
+		RefCBF* f = static_cast<RefCBF*>(p);
+		const int64_t n = (int64_t)f->size(); // counters = bytes; a multiple of 8 (CountingBloomFilter.hpp:34-45)
+		const int64_t nw = (n + 7) / 8;
+		uint64_t sum = 0, x = 0, nz = 0, ge = 0;
+#pragma omp parallel for schedule(static) reduction(+ : sum, nz, ge) reduction(^ : x)
+		for (int64_t i = 0; i < nw; ++i) {
+			uint64_t w = 0;
+			for (int64_t j = 0; j < 8 && 8 * i + j < n; ++j) {
+				const uint64_t c = (*f)[(size_t)(8 * i + j)];
+				w |= c << (8 * j);
+				nz += c != 0;
+				ge += c >= thr;
+			}
+			if (w) {
+				const uint64_t m = mix64((uint64_t)i + 1) | 1ULL;
+				sum += w * m;
+				x ^= mix64(w ^ m);
+			}
+		}
+		out4[0] = sum;
+		out4[1] = x;
+		out4[2] = nz;
+		out4[3] = ge;
+	}
+
+	// incrementAll over synthetic reads, OpenMP over reads: a saturating CAS loop per counter
+	// (CountingBloomFilter.hpp:165-183), so the bytes do not depend on the thread count
+	void ref_cbf_increment_all_synth(void* p, uint64_t seed, uint64_t first, uint64_t n, unsigned read_len)
+	{
+		RefCBF* f = static_cast<RefCBF*>(p);
+		const unsigned h = f->getHashNum(), k = f->getKmerSize();
+#pragma omp parallel
+		{
+			std::string s(read_len, 'A');
+#pragma omp for schedule(dynamic, 1024)
+			for (int64_t r = 0; r < (int64_t)n; ++r) {
+				synth_read(seed, first + (uint64_t)r, read_len, &s[0]);
+				ntHashIterator it(s, h, k);
+				while (it != ntHashIterator::end()) {
+					f->incrementAll(*it);
+					++it;
+				}
+			}
+		}
+	}
+	// k-mers of synthetic reads [first, first+n) with minCount >= threshold (CountingBloomFilter.hpp:190-196)
+	uint64_t ref_cbf_count_synth(void* p, uint64_t seed, uint64_t first, uint64_t n, unsigned read_len)
+	{
+		RefCBF* f = static_cast<RefCBF*>(p);
+		const unsigned h = f->getHashNum(), k = f->getKmerSize();
+		uint64_t hits = 0;
+#pragma omp parallel reduction(+ : hits)
+		{
+			std::string s(read_len, 'A');
+#pragma omp for schedule(dynamic, 1024)
+			for (int64_t r = 0; r < (int64_t)n; ++r) {
+				synth_read(seed, first + (uint64_t)r, read_len, &s[0]);
+				ntHashIterator it(s, h, k);
+				while (it != ntHashIterator::end()) {
+					hits += f->contains(*it) ? 1 : 0;
+					++it;
+				}
+			}
+		}
+		return hits;
+	}
+
+	// spaced seeds (BASELINE config 5): stHashIterator (vendor/stHashIterator.hpp:53-104) over synthetic reads into a
+	// BloomFilter constructed with hashNum = nseeds * h2; query != 0: returns the number of k-mers found instead
+	uint64_t ref_bf_spaced_synth(
+	    void* p,
+	    const char* const* seeds,
+	    unsigned nseeds,
+	    unsigned h2,
+	    uint64_t seed,
+	    uint64_t first,
+	    uint64_t n,
+	    unsigned read_len,
+	    int query)
+	{
+		RefBF* f = static_cast<RefBF*>(p);
+		const unsigned k = f->getKmerSize();
+		std::vector<std::string> ss;
+		for (unsigned i = 0; i < nseeds; ++i)
+			ss.push_back(seeds[i]);
+		const std::vector<std::vector<unsigned> > parsed = stHashIterator::parseSeed(ss);
+		uint64_t hits = 0;
+#pragma omp parallel reduction(+ : hits)
+		{
+			std::string s(read_len, 'A');
+#pragma omp for schedule(dynamic, 1024)
+			for (int64_t r = 0; r < (int64_t)n; ++r) {
+				synth_read(seed, first + (uint64_t)r, read_len, &s[0]);
+				stHashIterator it(s, parsed, nseeds, h2, k);
+				while (it != stHashIterator::end()) {
+					if (query)
+						hits += f->contains(*it) ? 1 : 0;
+					else
+						f->insert(*it);
+					++it;
+				}
+			}
+		}
+		return hits;
+	}
+
 	// serial (order-defined) counting-filter update over synthetic reads; op as ref_cbf_update
 	void ref_cbf_update_synth(void* p, uint64_t seed, uint64_t first, uint64_t n, unsigned read_len, int op)
 	{
@@ -342,7 +492,8 @@ extern "C"
 	// The hot loop of SURVEY.md section 3.1/3.2 over synthetic reads, OpenMP over reads.
 	// out[0]=insert seconds, out[1]=query seconds, out[2]=query hits, out[3]=k-mers per pass,
 	// out[4]=threads used, out[5]=popcount after insert (0 if skip_pop)
-	int ref_bench_bf(
+	// digest2 != NULL: also the digest (ref_bf_digest) of the filter the timed insert built
+	int ref_bench_bf_digest(
 	    uint64_t n_reads,
 	    unsigned read_len,
 	    unsigned k,
@@ -353,7 +504,8 @@ extern "C"
 	    int threads,
 	    int prefault,
 	    int skip_pop,
-	    double* out)
+	    double* out,
+	    uint64_t* digest2)
 	{
 		RefBF f(bits, h, k);
 #ifdef _OPENMP
@@ -407,7 +559,28 @@ extern "C"
 		out[3] = (double)kmers;
 		out[4] = (double)used;
 		out[5] = skip_pop ? 0.0 : (double)f.getPop();
+		if (digest2) {
+			uint64_t d3[3];
+			ref_bf_digest(&f, d3);
+			digest2[0] = d3[0];
+			digest2[1] = d3[1];
+		}
 		return 0;
+	}
+	int ref_bench_bf(
+	    uint64_t n_reads,
+	    unsigned read_len,
+	    unsigned k,
+	    unsigned h,
+	    uint64_t bits,
+	    uint64_t seed_ins,
+	    uint64_t seed_qry,
+	    int threads,
+	    int prefault,
+	    int skip_pop,
+	    double* out)
+	{
+		return ref_bench_bf_digest(n_reads, read_len, k, h, bits, seed_ins, seed_qry, threads, prefault, skip_pop, out, NULL);
 	}
 
 	// cost of generating the synthetic reads alone (to subtract from the loop above)

@@ -9,6 +9,7 @@
 #include "btlbf/stHashIterator.hpp"
 
 #include <atomic>
+#include <omp.h>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -549,6 +550,45 @@ static void contains_lookahead_is_invisible()
 		}
 	}
 	CHECK(wrong == 0);
+	// 7. a LONG sequence (the iterator announces tens of thousands of rows): the look-ahead fetches a window, not the
+	//    whole span, so the de-duplicating loop stays linear -- and two filters asked by turns keep their own answers.
+	//    Timed loosely: a refresh of the whole span per k-mer (the first version) needs minutes here.
+	{
+		std::string chrom;
+		for (unsigned r = 0; r < 400; ++r)
+			chrom += synth_read(6, r, L); // 60 000 bases, nothing of it in `bloom`
+		chrom += chrom.substr(0, 20000);  // ... and its first third once more
+		BloomFilter seen(1 << 26, h, k);
+		const double t0 = omp_get_wtime();
+		ntHashIterator itr(chrom, h, k);
+		size_t fresh = 0, again = 0, in_other = 0;
+		while (itr != itr.end()) {
+			if (!seen.contains(*itr)) {
+				seen.insert(*itr);
+				++fresh;
+			} else {
+				++again;
+			}
+			in_other += bloom.contains(*itr) ? 1 : 0; // a second filter about the same rows, by turns with the first
+			++itr;
+		}
+		const double dt = omp_get_wtime() - t0;
+		CHECK(fresh == 60000 - k + 1 + (k - 1)); // every window of the 60 000 bases + those across the seam
+		CHECK(again == 20000 - k + 1);
+		CHECK(in_other == 0);
+		CHECK(dt < 60.0);
+		std::printf("dedup loop over %zu bases: %.2f s\n", chrom.size(), dt);
+		// the same sequence again: everything is there now, one window of answers per 4096 rows
+		const double t1 = omp_get_wtime();
+		ntHashIterator again_itr(chrom, h, k);
+		size_t hits = 0;
+		while (again_itr != again_itr.end()) {
+			hits += seen.contains(*again_itr) ? 1 : 0;
+			++again_itr;
+		}
+		CHECK(hits == chrom.size() - k + 1);
+		CHECK(omp_get_wtime() - t1 < 10.0);
+	}
 }
 
 int main(int argc, char** argv)

@@ -8,6 +8,7 @@ popcounts and query bitmaps.  Position semantics: /root/reference/BloomFilter.hp
 import ctypes as C
 import numpy as np
 import pytest
+from conftest import require_hbm
 
 pytestmark = pytest.mark.gpu
 
@@ -168,8 +169,7 @@ def test_config4_real_geometry_one_shard_of_the_1tib_filter(bf):
 
     from btl_bloomfilter_amd.sharded import HipShardOps
 
-    if _free_gib() < 200:
-        pytest.skip("needs a 128 GiB shard plus scratch")
+    require_hbm(200 << 30, "a 128 GiB shard plus scratch")
     K, H, L, W = 31, 4, 150, 8
     n_reads, batch_reads = 1_500_000, 600_000  # three batches (the last one short), two windows each: six jobs
     reads = bf.synth_reads_device(42, 0, n_reads, L)
@@ -241,8 +241,7 @@ def test_single_gpu_256_gib_filter_2p41_bits(bf):
     batches are not worth a 512 GiB sweep), the forced partitioned path must still be exact."""
     import torch
 
-    if _free_gib() < 262:
-        pytest.skip("needs 256 GiB for the array plus scratch")
+    require_hbm(262 << 30, "a 256 GiB array plus scratch")
     bits, h, k, L = 1 << 41, 4, 31, 150
     reads = bf.synth_reads_device(42, 0, 2_000_000, L)
     f = bf.BloomFilter(bits, h, k)
@@ -346,8 +345,7 @@ def test_positions_of_filters_beyond_2p32_bits_of_no_power_of_two_size(bf, bits)
     (device_utils.hpp: every size above 2^32 that is no power of two): 3000 rows of 64-bit hashes, inserted as rows
     and looked up again; the array must hold exactly the bits Python's `%` says -- checked through the device-side
     digest and the popcount, the filter being far too large to download."""
-    if _free_gib() < bits / 8 / 2 ** 30 + 4:
-        pytest.skip("not enough free HBM")
+    require_hbm(bits // 8 + (4 << 30), "a filter of %d bits" % bits)
     rng = np.random.RandomState(bits % 9973)
     h = 3
     hv = rng.randint(0, 2 ** 63, size=(3000, h)).astype(np.uint64) * np.uint64(2) + rng.randint(0, 2, size=(3000, h)).astype(np.uint64)

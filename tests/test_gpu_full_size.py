@@ -8,6 +8,7 @@ What is matched: BloomFilter::insert / contains (BloomFilter.hpp:185-194,252-262
 CountingBloomFilter::incrementAll / contains (CountingBloomFilter.hpp:165-196), the stHashIterator-fed
 filter of config 5 (vendor/stHashIterator.hpp:53)."""
 import pytest
+from conftest import require_hbm
 
 pytestmark = pytest.mark.gpu
 
@@ -29,11 +30,7 @@ def bf():
 
 
 def need_hbm(nbytes):
-    import torch
-
-    free, _ = torch.cuda.mem_get_info()
-    if free < nbytes:
-        pytest.skip("needs %.0f GiB of free HBM" % (nbytes / 2**30))
+    require_hbm(nbytes, "a full-size parity test")
 
 
 def spliced_query(bf, reads, n, foreign, seed):

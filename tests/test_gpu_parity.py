@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, require_hbm
 
 pytestmark = pytest.mark.gpu
 
@@ -451,8 +451,7 @@ def test_full_size_filter_properties(bf):
 
     free, _ = torch.cuda.mem_get_info()
     bits = 1 << 39
-    if free < (bits // 8) + (8 << 30):
-        pytest.skip("not enough free HBM for a 64 GiB filter")
+    require_hbm((bits // 8) + (8 << 30), "a 64 GiB filter")
     k, h, L, n = 31, 4, 150, 200000
     flt = bf.BloomFilter(bits, h, k)
     reads = bf.synth_reads_device(42, 0, n, L)
@@ -1039,3 +1038,57 @@ def test_count_per_seq_matches_bitmaps(bf, oracle):
     torch.cuda.synchronize()
     assert int(hits.sum().item()) == int(cnt[1].item()) and bool((clean == L - k + 1).all().item())
     assert bool((hits[:1000] == L - k + 1).all().item()) and int(hits[1000:].max().item()) < L - k + 1
+
+
+def test_out_of_memory_mid_pass_gives_right_bytes_or_an_error_never_wrong_bytes(bf):
+    """HBM runs out while a partitioned pass wants its scratch (somebody else filled the card): the library must either
+    carry the operation out another way with the right result (the direct kernels need no scratch) or return an
+    error -- and stay usable afterwards.  Also exercised: a query that wants counts only needs a temporary hit bitmap
+    (run_query_like): no room for it is an error code, not a crash or a wrong count."""
+    import torch
+
+    from btl_bloomfilter_amd._lib import BtlbfError
+
+    bits, h, k, L, n = 1 << 33, 4, 31, 150, 2_000_000
+    reads = bf.synth_reads_device(42, 0, n, L)
+    a, b = bf.BloomFilter(bits, h, k), bf.BloomFilter(bits, h, k)
+    a.setInsertMode("direct")
+    a.insertSeqs(reads, read_len=L)
+    want = a.digest()
+    b.setInsertMode("partitioned")
+    b.setQueryMode("partitioned")
+    b.setProfiling(True)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(free - (96 << 20), dtype=torch.uint8, device="cuda")  # leaves far less than the scratch needs
+    try:
+        outcome = "ok"
+        try:
+            b.insertSeqs(reads, read_len=L)
+            torch.cuda.synchronize()
+        except BtlbfError as exc:
+            outcome = "error: %s" % exc
+        if outcome == "ok":
+            prof = b.getProfile()
+            assert "insert_hash" not in prof and prof.get("insert_direct", (0, 0))[1] >= 1, prof
+            assert b.digest() == want
+        try:
+            _, _, cnt = b.containsSeqs(reads, read_len=L, want_valid=False, want_counts=True)
+            torch.cuda.synchronize()
+            if outcome == "ok":
+                assert cnt.tolist() == [n * (L - k + 1)] * 2
+        except BtlbfError as exc:
+            assert "memory" in str(exc).lower() or "hipMalloc" in str(exc) or "alloc" in str(exc), str(exc)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    # with the memory back the same objects work as if nothing had happened
+    b.clear()
+    b.insertSeqs(reads, read_len=L)
+    torch.cuda.synchronize()
+    prof = b.getProfile()
+    assert prof.get("insert_hash", (0, 0))[1] >= 1, prof
+    assert b.digest() == want
+    _, _, cnt = b.containsSeqs(reads, read_len=L, want_valid=False, want_counts=True)
+    assert cnt.tolist() == [n * (L - k + 1)] * 2
