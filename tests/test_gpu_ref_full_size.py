@@ -151,7 +151,7 @@ def test_c5_spaced_seeds_bit_exact_against_the_reference_at_2p37_bits(bf, ref):
     rf.spaced_synth(C5_SEEDS, 1, 42, 0, n, L)
     want = rf.digest()
     want_pop = rf.last_pop
-    assert 0.999 * n * 120 * 4 < want_pop <= n * 120 * 4
+    assert 0.99 * n * 120 * 4 < want_pop <= n * 120 * 4  # ~0.35 % of the probes collide at this load
 
     reads = bf.synth_reads_device(42, 0, n, L)
     a, b = bf.BloomFilter(bits, 4, k), bf.BloomFilter(bits, 4, k)
