@@ -172,7 +172,7 @@ C5_SEEDS = ["1110111011101110111011101110111", "1101101101101101011011011011011"
             "1111001111001111111001111001111", "1011101011101011101011101011101"]
 
 
-def side_configs(m, torch, reads, n_reads, dev):
+def side_configs(m, torch, reads, n_reads, dev, only=None):
     """The other BASELINE configurations and the reference's everyday shapes (ragged sequences as its FASTA loader
     produces them, Tests/AdHoc/ParallelFilter.cpp:104-122; a filter size from calcOptimalSize, BloomFilter.hpp:413-421,
     i.e. no power of two), each run on THIS box after the timed region: one warm-up pass (scratch allocation), then
@@ -181,6 +181,8 @@ def side_configs(m, torch, reads, n_reads, dev):
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 
     def run(name, make, insert, query, kmers, reps=2, note=None, extra=None):
+        if only and name not in only:
+            return
         try:
             f = make()
             f.setProfiling(True)
@@ -236,6 +238,8 @@ def side_configs(m, torch, reads, n_reads, dev):
         lambda f: q(f, read_len=L), n_reads * (L - K + 1), note="C2's reads, 3*2^37 bits (48 GiB): hash % size by multiplication")
     # ragged sequences (lengths 100..200) over the same bases
     try:
+        if only and "C2_ragged" not in only:
+            raise StopIteration
         g = torch.Generator(device=dev)
         g.manual_seed(1)
         lens = torch.randint(100, 201, (n_reads + n_reads // 8,), device=dev, generator=g, dtype=torch.int64)
@@ -250,6 +254,8 @@ def side_configs(m, torch, reads, n_reads, dev):
             lambda f: q(f, starts=starts), kmers_r,
             note="C2's bases cut into %d sequences of 100..200 bases (btlbf_layout::starts), 2^39 bits" % n_seq)
         del starts
+    except StopIteration:
+        pass
     except Exception as exc:
         out["C2_ragged"] = {"error": repr(exc)}
     # C3: counting filter; incrementAll + contains through the partitioned pipeline, then the reference's default
@@ -264,6 +270,8 @@ def side_configs(m, torch, reads, n_reads, dev):
     if "query_Mkmers_s" in out.get("C3_incrementAll", {}):
         out["C3_incrementAll"]["query_Mkmers_s"] /= 2  # one query pass per timed rep, over km3 k-mers
     try:
+        if only and "C3_insert" not in only:
+            raise StopIteration
         cb = m.CountingBloomFilter(1 << 35, hc, kc, 2)
         t = []
         for _ in range(2):
@@ -279,6 +287,8 @@ def side_configs(m, torch, reads, n_reads, dev):
                             "note": "CountingBloomFilter::insert = conservative update (incrementMin), parallel mode: "
                                     "every read set inserted twice; all k-mers must pass threshold 2 afterwards"}
         del cb
+    except StopIteration:
+        pass
     except Exception as exc:
         out["C3_insert"] = {"error": repr(exc)}
     torch.cuda.empty_cache()

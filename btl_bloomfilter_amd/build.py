@@ -38,8 +38,16 @@ def stale():
     return _newest_header() > t or any(os.path.getmtime(os.path.join(CSRC, src)) > t for _, src, _ in UNITS)
 
 
+# BTLBF_BUILD_UNITS=part_hash_h4,... (diagnostic variants only): compile just these units with the variant's flags and
+# link the product build's objects for the rest -- a kernel experiment then costs one translation unit, not thirteen
+ONLY = [u for u in os.environ.get("BTLBF_BUILD_UNITS", "").split(",") if u] if TAG else []
+MAIN_OBJ = os.path.join(HERE, "_build")
+
+
 def _compile(unit, hipcc, force, verbose):
     name, src, extra = unit
+    if ONLY and name not in ONLY:
+        return os.path.join(MAIN_OBJ, name + ".o")
     obj = os.path.join(OBJ, name + ".o")
     srcp = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _newest_header()):
@@ -54,7 +62,7 @@ def _compile(unit, hipcc, force, verbose):
 
 
 def build(force=False, verbose=False, jobs=None):
-    if not force and not stale():
+    if not force and not ONLY and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)

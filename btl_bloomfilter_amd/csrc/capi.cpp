@@ -476,15 +476,40 @@ int build_spaced(HashParams& hp, const char* const* seeds, unsigned n_seeds, uns
 				dc.push_back((uint16_t)i);
 	}
 	hp.dc_off[n_seeds] = (uint32_t)dc.size();
+	// the union list (internal.hpp HashParams::dcu): distinct offsets with their seed masks, those of every seed first
+	std::vector<uint32_t> dcu;
+	{
+		std::map<unsigned, uint32_t> mask_of;
+		for (unsigned j = 0; j < n_seeds; ++j)
+			for (uint32_t d = hp.dc_off[j]; d < hp.dc_off[j + 1]; ++d)
+				mask_of[dc[d]] |= 1u << j;
+		const uint32_t all = n_seeds >= 32 ? 0xffffffffu : (1u << n_seeds) - 1;
+		for (const auto& kv : mask_of)
+			if (kv.second == all)
+				dcu.push_back(kv.first | (kv.second << 16));
+		hp.n_dcu_all = (uint32_t)dcu.size();
+		for (const auto& kv : mask_of)
+			if (kv.second != all)
+				dcu.push_back(kv.first | (kv.second << 16));
+		if (dcu.size() > kMaxDcu) {
+			dcu.clear();
+			hp.n_dcu_all = 0;
+		}
+		hp.n_dcu = (uint32_t)dcu.size();
+	}
+	const size_t dc_bytes = (dc.size() * 2 + 15) / 16 * 16;
 	*d_pos = nullptr;
-	HIP_TRY(hipMalloc((void**)d_dc, dc.size() * 2 + 16));
+	HIP_TRY(hipMalloc((void**)d_dc, dc_bytes + dcu.size() * 4 + 16));
 	if (!dc.empty())
 		HIP_TRY(hipMemcpy(*d_dc, dc.data(), dc.size() * 2, hipMemcpyHostToDevice));
+	if (!dcu.empty())
+		HIP_TRY(hipMemcpy(reinterpret_cast<uint8_t*>(*d_dc) + dc_bytes, dcu.data(), dcu.size() * 4, hipMemcpyHostToDevice));
 	hp.n_seeds = n_seeds;
 	hp.h2 = h2;
 	hp.h = n_seeds * h2;
 	hp.use_pos_tab = 1; // spaced seeds are masked through the positional table (k <= 1024 checked above)
 	hp.dc_idx = *d_dc;
+	hp.dcu = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(*d_dc) + dc_bytes);
 	return BTLBF_OK;
 }
 
@@ -1698,7 +1723,7 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 		return false;
 	if (f->kind == BTLBF_COUNTING8 ? counting_op != BTLBF_INCREMENT_ALL : f->kind != BTLBF_BLOOM)
 		return false;
-	if (!part_supported_h(f->hp.h) || len == 0)
+	if (!part_supported(f->hp) || len == 0)
 		return false;
 	if (f->insert_mode == BTLBF_INSERT_PARTITIONED)
 		return true;
@@ -1957,7 +1982,7 @@ int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, 
 	*yes = false;
 	if (f->query_mode == BTLBF_INSERT_DIRECT)
 		return BTLBF_OK;
-	if (!part_supported_h(f->hp.h) || base.len == 0)
+	if (!part_supported(f->hp) || base.len == 0)
 		return BTLBF_OK;
 	if (f->query_mode == BTLBF_INSERT_PARTITIONED) {
 		*yes = true;
@@ -2008,7 +2033,7 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 	// window through the WINDOW kernels; want_partitioned_query decides for it)
 	if (f->shard_count != 1 || f->mod.shard_lo != 0 || f->mod.shard_len != f->mod.size)
 		return BTLBF_OK;
-	if (f->query_mode != BTLBF_INSERT_AUTO || !L || L < k || L < 8 || f->hp.n_seeds || !part_supported_h(f->hp.h))
+	if (f->query_mode != BTLBF_INSERT_AUTO || !L || L < k || L < 8 || f->hp.n_seeds || !part_supported(f->hp))
 		return BTLBF_OK;
 	const uint64_t n_reads = a.len / L;
 	const uint32_t W = L - k + 1;
@@ -2189,7 +2214,7 @@ int route_plan(const btlbf_filter* f, uint64_t len, const LayoutParams& lay, uns
 	const uint64_t M = f->mod.size;
 	if (!f->mod.pow2 || n_shards == 0 || (n_shards & (n_shards - 1)) || n_shards > 1024)
 		return fail(BTLBF_EINVAL, "routing needs a filter whose global size and shard count are powers of two");
-	if (!part_supported_h(f->hp.h) || !part_hash_fits(f->hp, 1024))
+	if (!part_supported(f->hp) || !part_hash_fits(f->hp, 1024))
 		return fail(BTLBF_EINVAL, "routing does not support this hash configuration");
 	const unsigned lm = ceil_log2(M);
 	unsigned max_window = 42; // BTLBF_ROUTE_WINDOW_BITS exists for tests: small filters then exercise several windows

@@ -66,7 +66,15 @@ struct HashParams {
 	// indices, seed j uses [dc_off[j], dc_off[j+1]); they are XORed back out through pos_tab
 	const uint16_t* dc_idx;
 	uint32_t dc_off[kMaxSeeds + 1];
+	// the same don't-care positions as ONE list of distinct offsets, each with the set of seeds that leave it out:
+	// dcu[u] = offset | seed mask << 16 (device memory behind dc_idx), the first n_dcu_all of them left out by EVERY
+	// seed.  A window's positional-table term for an offset is the same whichever seed asks for it, so the pass-A
+	// hash stage fetches it once per offset and XORs it into the seeds of the mask (seq_core.hpp); n_dcu == 0: list
+	// not available (more than kMaxDcu = 64 offsets: the kernels keep the list in one register of a wave), the per-seed lists above are walked instead.
+	const uint32_t* dcu;
+	uint32_t n_dcu, n_dcu_all;
 };
+static constexpr uint32_t kMaxDcu = 64;
 
 // Sequence boundaries inside a buffer (btlbf_layout, device-resident form).
 struct LayoutParams {
@@ -136,6 +144,10 @@ struct SeqArgs {
 	uint32_t rg_lpad;  // bytes a read occupies in the LDS tile (read_len rounded up to 8)
 	uint32_t rg_cap;   // bytes of dynamic LDS the tile image takes (reads + guard + two window bitmaps)
 	uint32_t rg_lpad_inv; // floor(2^32 / rg_lpad) + 1: x / rg_lpad == umulhi(x, rg_lpad_inv) for the offsets of a tile
+	// ragged layout in pass A's overlapped schedule: words of the LDS bitmap (behind the tile image) in which the
+	// staging waves mark the sequence starts of the NEXT tile while the current one is partitioned (0: none -- the
+	// starts are marked after the staging, between two more barriers per tile)
+	uint32_t sb_words;
 };
 
 // How pass A cuts a buffer into tiles (partition_kernels.hip: part_tiling).  All host-side planning is in
@@ -200,7 +212,7 @@ static inline uint32_t part_late_cap() { return 32768u; }
 
 // launchers (defined in the .hip files)
 PartTiling part_tiling(const HashParams& hp, uint32_t p0, const LayoutParams& lay, uint64_t len);
-bool part_supported_h(uint32_t h);
+bool part_supported(const HashParams& hp); // can pass A hash this configuration (1..8 hashes; spaced seeds: the union list)
 bool part_hash_fits(const HashParams& hp, uint32_t p0);
 uint32_t part_hash_regions(const HashParams& hp, uint32_t p0, uint32_t cus); // pass A workgroups = regions per bin
 hipError_t launch_part_hash(const SeqArgs& a, const PartOut& out, uint32_t bin_shift, const PartSide& sd, int query,

@@ -35,8 +35,8 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 	const uint32_t tile_cap = grid ? a.rg_cap : seq_tile_cap(kTile, k);
 	const uint32_t tile_bytes = grid ? a.rg_reads * a.layout.read_len : (uint32_t)kTile; // window starts per tile
 	uint8_t* tile = dyn;
-	uint8_t* spaced_lds = dyn + tile_cap;
-	uint8_t* part_base = dyn + tile_cap + seq_spaced_bytes(a.hp);
+	uint8_t* spaced_lds = dyn + tile_cap + a.sb_words * 4; // (the overlapped schedule's start bitmap: not used here)
+	uint8_t* part_base = spaced_lds + seq_spaced_bytes(a.hp);
 	PartLds pl{};
 	PartLdsS ps{};
 	if (SMALL) {
@@ -257,12 +257,20 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	const uint32_t tile_cap = grid ? a.rg_cap : seq_tile_cap(kTile, k);
 	const uint32_t tile_bytes = grid ? a.rg_reads * a.layout.read_len : (uint32_t)kTile; // window starts per tile
 	uint8_t* tile = dyn;
-	uint8_t* spaced_lds = dyn + tile_cap;
-	const PartLds pl = part_carve(dyn + tile_cap + seq_spaced_bytes(a.hp), out.P);
+	// ragged layout: one bit per staged byte of the NEXT tile, set where a sequence starts (see `mark_ahead` below)
+	uint32_t* const sbm = reinterpret_cast<uint32_t*>(dyn + tile_cap);
+	const bool sb = a.sb_words != 0;
+	__shared__ uint32_t sb_cnt; // starts of the tile being marked that lie at or before the start of the one after it
+	uint8_t* spaced_lds = dyn + tile_cap + a.sb_words * 4;
+	const PartLds pl = part_carve(spaced_lds + seq_spaced_bytes(a.hp), out.P);
 	part_init<kPartThreads>(pl, out.P);
 	seq_setup_tables<NT, SPACED>(sh, a.hp, spaced_lds);
-	if (tid == 0)
+	if (tid == 0) {
 		p2_done = 0;
+		sb_cnt = 0;
+	}
+	for (uint32_t i = tid; i < a.sb_words; i += NT)
+		sbm[i] = 0;
 	uint32_t* const late0 = sd.late_buf + (uint64_t)blockIdx.x * 2 * sd.late_cap; // this workgroup's two late images
 
 	uint32_t* words = static_cast<uint32_t*>(a.filter);
@@ -310,8 +318,49 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			seq_stage_convert_grid<NY, kStageKW>(raw, tile, sh, a.seq, a.len, L, a.rg_lpad, tile_bytes, g0, ytid);
 		else
 			seq_stage_convert<NY, kStageKW, false, false, true>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off,
-			                                                    span, ytid);
+			                                                    span, ytid, sb && t != t_begin ? sbm : nullptr);
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
+	};
+	// Ragged layout with a start bitmap: the staging waves mark the sequence starts of tile T in `sbm` one segment
+	// before they convert it (round 1 of tile T - 1: the round's first barrier lies in between), and the conversion
+	// clears the "good" flags from the bitmap -- no barrier of its own, no search: the index of the first start behind
+	// a tile's first byte runs along (s_base; the marking counts the starts up to the next tile's first byte).  The
+	// first plan marked the starts after the staging, between two more barriers per tile, behind a binary search of
+	// starts[] by one thread: pass A took 65 ms per 6x10^9 k-mers of 100..200-base sequences instead of 47.
+	uint64_t s_base = 0;
+	// the first candidate of every staging thread is requested together with the tile's words (before phase 1's stores)
+	auto starts_request = [&](uint64_t& p_mine, uint64_t& p_last) {
+		const uint64_t s = s_base + (uint32_t)ytid, sl = s_base + (uint32_t)(NY - 1);
+		p_mine = s <= a.layout.n_seqs ? a.layout.starts[s] : ~0ull;
+		p_last = sl <= a.layout.n_seqs ? a.layout.starts[sl] : ~0ull; // (one address per wave)
+	};
+	auto mark_ahead = [&](uint64_t T, uint64_t p, const uint64_t p_last) {
+		const uint64_t g0 = T * (uint64_t)tile_bytes;
+		uint64_t need = a.len > g0 ? a.len - g0 : 0;
+		if (need > span)
+			need = span;
+		const uint64_t end = g0 + need, nxt = g0 + tile_bytes;
+		const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(a.seq + g0) & 3);
+		uint32_t cnt = 0;
+		uint64_t s = s_base + (uint32_t)ytid, sl = s_base + (uint32_t)(NY - 1), pl = p_last;
+		for (;;) {
+			const bool in = p < end;
+			if (in && p > g0) {
+				const uint32_t li = (uint32_t)(p - g0) + mis;
+				atomicOr(&sbm[li >> 5], 1u << (li & 31));
+			}
+			cnt += (uint32_t)__popcll(__ballot(in && p <= nxt));
+			// more than NY starts in one tile (sequences shorter than 16 bytes): every thread looks NY further on
+			// (the test is the same in all lanes: the wave stays together for the ballot)
+			if (!(pl < end))
+				break;
+			s += NY;
+			sl += NY;
+			p = s <= a.layout.n_seqs ? a.layout.starts[s] : ~0ull;
+			pl = sl <= a.layout.n_seqs ? a.layout.starts[sl] : ~0ull;
+		}
+		if ((ytid & 63) == 0 && cnt)
+			atomicAdd(&sb_cnt, cnt);
 	};
 	// ragged layout: sequence starts inside the freshly staged tile t (all threads; two barriers)
 	auto mark_starts = [&](uint64_t t) {
@@ -330,8 +379,22 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			stage_convert(t_begin);
 		}
 		__syncthreads();
-		if (a.layout.starts)
+		if (a.layout.starts) {
 			mark_starts(t_begin);
+			if (sb && tid == 0) {
+				// where the marking of the second tile begins: the first start behind that tile's first byte
+				const uint64_t g1 = (t_begin + 1) * (uint64_t)tile_bytes;
+				uint64_t lo = 0, hi = a.layout.n_seqs + 1;
+				while (lo < hi) {
+					const uint64_t mid = (lo + hi) >> 1;
+					if (a.layout.starts[mid] > g1)
+						hi = mid;
+					else
+						lo = mid + 1;
+				}
+				sh.start_lo = lo; // (read two barriers further on)
+			}
+		}
 	}
 
 	LaneState st;
@@ -441,6 +504,17 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 		const uint64_t g0 = t * (uint64_t)tile_bytes;
 		li0 = grid ? grid_li0 : tid * kPartW + (uint32_t)(reinterpret_cast<uintptr_t>(a.seq + g0) & 3);
 		vmask = 0;
+		if (sb && isY) {
+			// the start bitmap was read by the conversion of this tile (two barriers ago) and is marked again in this
+			// tile's second round (two barriers on)
+			uint32_t yt = (uint32_t)ytid;
+			asm volatile("" : "+v"(yt));
+			for (uint32_t i = yt; i < a.sb_words; i += NY)
+				sbm[i] = 0;
+			if (yt == 0)
+				sb_cnt = 0;
+		}
+		uint64_t sp_mine = ~0ull, sp_last = ~0ull;
 		// (unrolled: with one rolled copy of the round the register allocator spills inside the loop)
 #pragma unroll
 		for (uint32_t r = 0; r < 2; ++r) {
@@ -454,9 +528,19 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 				// memory operation pending" in front of the loads would also wait for the stores of late entries,
 				// and the X waves would find the Y waves still there when they arrive at the barrier
 				stage_request(t + 1);
+				if (sb) {
+					if (t == t_begin) { // (uniform: kept in scalar registers)
+						const uint64_t v = sh.start_lo;
+						s_base = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v) |
+						         ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+					}
+					starts_request(sp_mine, sp_last);
+				}
 			}
 			OV_STAMP(9);
 			part_round_p1_late<E, WINDOW ? 1 : H, WINDOW>(pl, bin, val, live, late0 + (uint64_t)r * sd.late_cap, ovf);
+			if (sb && r == 1 && isY && t + 1 < t_end)
+				mark_ahead(t + 1, sp_mine, sp_last);
 			OV_STAMP(0);
 			__syncthreads(); // (round 1: nobody reads this tile's image any more)
 			OV_STAMP(1);
@@ -464,10 +548,13 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			if (!isY) {
 				part_round_p2<NT, kOvOwners>(pl, out, 0, blockIdx.x, ovf, &p2_done);
 			} else {
-				if (r == 0)
+				if (r == 0) {
 					hash_hi(); // ahead of the X waves: this wave's entries of round 1
-				else if (t + 1 < t_end)
+				} else if (t + 1 < t_end) {
 					stage_convert(t + 1);
+					if (sb)
+						s_base += __builtin_amdgcn_readfirstlane(sb_cnt); // complete since the barrier; zeroed at the top of the next tile
+				}
 				late_fetch(r, (uint32_t)(t - t_begin) * 2 + r);
 			}
 			OV_STAMP(2);
@@ -511,7 +598,7 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			}
 		}
 		my_valid += __popc(vmask);
-		if (a.layout.starts && t + 1 < t_end)
+		if (a.layout.starts && !sb && t + 1 < t_end)
 			mark_starts(t + 1);
 	}
 #ifdef BTLBF_PHASE_STAMPS
@@ -546,17 +633,24 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t b
 	// query per 3.6x10^9 k-mers against 34.3 / 35.1 with the plain kernel, h = 6: 52.2 / 62.2 against 41.7 / 42.6,
 	// h = 8: 230 / 257 against 97 / 169; h = 3: 19.5 / 20.3 against 21.3 / 21.8)
 	constexpr bool kOvH = H <= 4;
-	const bool overlapped = !SMALL && kOvH && !spaced && out.P <= 64u * kOvOwners && !ov_off && sd.late_buf != nullptr &&
+	// (spaced seeds keep the plain schedule: the overlapped kernel runs them, bit-identically, but 9 % slower -- 99.7
+	// against 91.3 ms per 6x10^9 k-mers at BASELINE config 5 -- its registers are full without the seeds' running values)
+#ifdef BTLBF_OV_SPACED
+	constexpr bool kOvSpaced = true;
+#else
+	constexpr bool kOvSpaced = false;
+#endif
+	const bool overlapped = !SMALL && kOvH && (!spaced || kOvSpaced) && out.P <= 64u * kOvOwners && !ov_off && sd.late_buf != nullptr &&
 	                        sd.late_cap >= kStageEntries;
 #define BTLBF_PLAUNCH(P, S, W)                                                                                      \
 	do {                                                                                                            \
-		if constexpr (!SMALL && !S && kOvH) {                                                                       \
+		if constexpr (!SMALL && (!S || kOvSpaced) && kOvH) {                                                        \
 			if (overlapped) {                                                                                       \
-				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, false, Q, W>), \
+				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, S, Q, W>), \
 				                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);            \
 				if (e != hipSuccess)                                                                                \
 					return e;                                                                                       \
-				hipLaunchKernelGGL((part_hash_ov_kernel<H, P, false, Q, W>), dim3(out.regions), dim3(NT), dyn, s, a, out, \
+				hipLaunchKernelGGL((part_hash_ov_kernel<H, P, S, Q, W>), dim3(out.regions), dim3(NT), dyn, s, a, out, \
 				                   bin_shift, sd);                                                                  \
 				break;                                                                                              \
 			}                                                                                                       \

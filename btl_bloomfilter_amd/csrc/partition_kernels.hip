@@ -573,7 +573,9 @@ static hipError_t launch_hash_any(const SeqArgs& a, const PartOut& out, uint32_t
 	}
 }
 
-bool part_supported_h(uint32_t h) { return h >= 1 && h <= 8; }
+// 1..8 hashes per k-mer; spaced seeds only with the union list of don't-care offsets (HashParams::dcu: at most 64
+// distinct offsets -- the hash stage keeps the list in one register of a wave); anything else stays on the direct kernels
+bool part_supported(const HashParams& hp) { return hp.h >= 1 && hp.h <= 8 && (hp.n_seeds == 0 || hp.n_dcu > 0); }
 
 // pass A over tiles [a.first_tile, +a.n_tiles) in the units of part_tiling() for this buffer; exactly
 // out.regions workgroups are launched (one region each; idle ones still publish empty counts)
@@ -583,10 +585,23 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bi
 	SeqArgs a = a_in;
 	if (a.n_tiles == 0)
 		return hipSuccess;
+	if (!part_supported(a.hp))
+		return hipErrorInvalidValue;
 	PartFront fr;
 	PartGrid g;
 	const bool grid = part_read_grid(a.hp, out.P, a.layout, &g);
-	if (!part_front(a.hp, out.P, fr, grid ? g.cap : 0))
+	// ragged layout: room for the start bitmap of the overlapped schedule behind the tile image, if the LDS has it
+	// without giving up the positional table (part_hash_inst.hip; the plain kernels leave it unused)
+	a.sb_words = 0;
+	if (a.layout.starts && !grid && !part_want_small(out.P)) {
+		PartFront plain;
+		const uint32_t words = ((uint32_t)kPartTile + a.hp.k + 2 + 31) / 32, cap = seq_tile_cap(kPartTile, a.hp.k);
+		const uint32_t sb_bytes = (words * 4 + 15) / 16 * 16;
+		if (part_front(a.hp, out.P, plain) && part_front(a.hp, out.P, fr, cap + sb_bytes) && !fr.small &&
+		    fr.use_pos_tab == plain.use_pos_tab)
+			a.sb_words = sb_bytes / 4;
+	}
+	if (!part_front(a.hp, out.P, fr, grid ? g.cap : a.sb_words ? seq_tile_cap(kPartTile, a.hp.k) + a.sb_words * 4 : 0))
 		return hipErrorInvalidValue;
 	a.rg_reads = g.reads;
 	a.rg_gpr = g.gpr;

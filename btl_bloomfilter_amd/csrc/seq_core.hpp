@@ -14,6 +14,16 @@
 #pragma once
 #include "device_utils.hpp"
 
+#ifndef BTLBF_SPACED_GRP
+#define BTLBF_SPACED_GRP 2
+#endif
+#ifndef BTLBF_SPACED_CHK
+#define BTLBF_SPACED_CHK 2
+#endif
+#ifndef BTLBF_SPACED_U8
+#define BTLBF_SPACED_U8 1
+#endif
+
 namespace btlbf {
 
 static constexpr int kW = 8; // consecutive windows per lane (default)
@@ -61,9 +71,14 @@ __host__ __device__ inline uint32_t seq_pos_tab_bytes(const HashParams& hp)
 {
 	return hp.use_pos_tab ? hp.k * kNumCodes * 16 : 0;
 }
+__host__ __device__ inline uint32_t seq_dc_list_bytes(const HashParams& hp)
+{
+	return hp.n_seeds ? ((hp.dc_off[hp.n_seeds] * 2 + 15) / 16) * 16 : 0;
+}
+// ... followed by the union list of distinct don't-care offsets (HashParams::dcu), 4 bytes each
 __host__ __device__ inline uint32_t seq_spaced_bytes(const HashParams& hp)
 {
-	return seq_pos_tab_bytes(hp) + (hp.n_seeds ? ((hp.dc_off[hp.n_seeds] * 2 + 15) / 16) * 16 : 0);
+	return seq_pos_tab_bytes(hp) + seq_dc_list_bytes(hp) + (hp.n_seeds ? ((hp.n_dcu * 4 + 15) / 16) * 16 : 0);
 }
 
 // one-time table setup; callers __syncthreads() before first use (seq_stage_tile does)
@@ -98,6 +113,9 @@ __device__ __forceinline__ void seq_setup_tables(SeqShared& sh, const HashParams
 		const uint32_t ndc = hp.dc_off[hp.n_seeds];
 		for (uint32_t i = tid; i < ndc; i += NT)
 			di[i] = hp.dc_idx[i];
+		uint32_t* du = reinterpret_cast<uint32_t*>(spaced_lds + seq_pos_tab_bytes(hp) + seq_dc_list_bytes(hp));
+		for (uint32_t i = tid; i < hp.n_dcu; i += NT)
+			du[i] = hp.dcu[i];
 	}
 }
 
@@ -195,7 +213,8 @@ template <int NT, int KW = kW, bool LEAD_BARRIER = true, bool TRAIL_BARRIER = tr
 __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, uint8_t* tile, uint32_t tile_cap,
                                                       SeqShared& sh, const uint8_t* seq, uint64_t len,
                                                       const LayoutParams& lay, uint32_t k, uint64_t g0,
-                                                      uint32_t tile_off, uint32_t span = 0, int32_t tid_in = -1)
+                                                      uint32_t tile_off, uint32_t span = 0, int32_t tid_in = -1,
+                                                      const uint32_t* start_bits = nullptr)
 {
 	static_assert(!NOSYNC || (!LEAD_BARRIER && !TRAIL_BARRIER), "no barriers at all when only some waves stage");
 	constexpr uint32_t kTileW = NT * KW;
@@ -258,6 +277,12 @@ __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, u
 					rr = (rr + 1 == L) ? 0 : rr + 1;
 				}
 			}
+		}
+		if (start_bits) {
+			// ragged layout, sequence starts of this tile marked beforehand in an LDS bitmap (one bit per staged byte;
+			// pass A's overlapped schedule): the four bits of this word clear the "good" flags of its bytes
+			const uint32_t b4 = (start_bits[j >> 3] >> ((j & 7u) * 4u)) & 0xfu;
+			o &= ~(((b4 * 0x00204081u) & 0x01010101u) * kBaseGood);
 		}
 		reinterpret_cast<uint32_t*>(tile)[j] = o;
 	};
@@ -473,9 +498,21 @@ __device__ __forceinline__ void seq_lane_range(const uint8_t* tile, const SeqSha
 				rh = sror1(rh) ^ tt.y;
 			}
 		}
-		// bases leaving (ob: li0 .. li0+7) and entering (ib: li0+k .. li0+k+7) the lane's windows
+		// bases leaving (ob: li0 .. li0+7) and entering (ib: li0+k .. li0+k+7) the lane's windows.  li0 is a multiple of
+		// four unless the caller's buffer is misaligned, li0 + k rarely is: three aligned words and two byte-wise funnel
+		// shifts (the shift is the same in every lane) instead of one misaligned 8-byte read, which this chip replays
 		st.ob = lds_u64(bp);
+#ifdef BTLBF_IB_UNALIGNED
 		st.ib = lds_u64(bp + k);
+#else
+		{
+			const uint32_t a = li0 + k, sh = a & 3u;
+			const uint32_t* w = reinterpret_cast<const uint32_t*>(tile + (a & ~3u));
+			const uint32_t d0 = w[0], d1 = w[1], d2 = w[2]; // (inside the image: seq_tile_cap leaves 15 bytes of slack)
+			const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+			st.ib = ((uint64_t)hi << 32) | lo;
+		}
+#endif
 		st.first_valid = (uint32_t)st.ob & kBaseValid;
 		st.good = good - (((uint32_t)st.ob / kBaseGood) & 1);
 		st.fh = fh;
@@ -484,6 +521,190 @@ __device__ __forceinline__ void seq_lane_range(const uint8_t* tile, const SeqSha
 	uint64_t fh = st.fh, rh = st.rh;
 	const uint64_t ob = st.ob, ib = st.ib;
 	uint32_t good = st.good, first_valid = st.first_valid;
+	if constexpr (SPACED && HS > 0) {
+		// Spaced seeds, one hash per seed, seed count known at compile time (pass A): the windows are walked in groups of
+		// GRP.  The term a don't-care position contributes -- pos_tab[offset][base] -- is the same whichever seed leaves
+		// that position out, and the GRP windows of a group read GRP consecutive bases at every offset.  So per DISTINCT
+		// offset (HashParams::dcu; 23 for BASELINE config 5's four seeds, whose own lists add up to 35): one LDS read of
+		// the GRP bases, one table entry per window, and XORs into exactly the seeds of the offset's mask (the mask is
+		// uniform: scalar branches).  Offsets left out by EVERY seed go into the common base first.  Against the per-seed
+		// walk below (a byte read, a table read and two 64-bit XORs per seed, window and position): a third fewer LDS
+		// table reads, an eighth of the byte reads, no address arithmetic per seed.
+		// HS > 0 is pass A, whose host side takes spaced seeds only when the union list exists (part_supported); the
+		// per-seed walk below is then dead code for this instantiation and costs it no registers
+		{
+			// (groups of two windows: four need 96 registers for the seeds' running values and the two table buffers,
+			// and pass A then spills 80 bytes per lane; two cost the same instructions per window bar the loop control)
+			constexpr int GRP = BTLBF_SPACED_GRP;
+			static_assert((W1 - W0) % GRP == 0 && W0 % GRP == 0, "whole groups of windows");
+			const uint32_t* dcu = reinterpret_cast<const uint32_t*>(spaced_lds + seq_pos_tab_bytes(hp) + seq_dc_list_bytes(hp));
+			const uint32_t n_all = hp.n_dcu_all, n_dcu = hp.n_dcu;
+			static_assert(kMaxDcu == 64, "the union list is held in one register of a wave");
+#pragma unroll
+			for (int g0 = W0; g0 < W1; g0 += GRP) {
+				uint64_t bf[GRP], br[GRP];
+				bool okw[GRP];
+#pragma unroll
+				for (int q = 0; q < GRP; ++q) {
+					const int w = g0 + q;
+					if (w > 0) {
+						const uint32_t eo = (uint32_t)(ob >> (8 * (w - 1))) & 0xffu;
+						const uint32_t ei = (uint32_t)(ib >> (8 * (w - 1))) & 0xffu;
+						const uint32_t en = (uint32_t)(ob >> (8 * w)) & 0xffu;
+						const U64x2 tt = tab16(sh.pair_tab, ((eo & kCodeOff) * kNumCodes) | (ei & kCodeOff));
+						fh = srol1(fh) ^ tt.x;
+						rh = sror1(rh ^ tt.y);
+						good += (ei / kBaseGood) & 1;
+						good -= (en / kBaseGood) & 1;
+						first_valid = en & kBaseValid;
+					}
+					okw[q] = first_valid && good == k - 1;
+					bf[q] = fh;
+					br[q] = rh;
+				}
+				// The list sits in ONE register of the wave (lane u holds entry u; kMaxDcu = 64) and an entry is fetched with
+				// v_readlane (uniform, no memory access).  Offsets are taken CHK at a time: the CHK reads of the windows' bases
+				// go out together, then the CHK x GRP table reads, then the XORs -- two LDS latencies per CHK offsets.  (One
+				// offset at a time, base read -> table reads -> XORs, left three dependent LDS round trips per offset with
+				// forty instructions to cover them; a two-deep software pipeline did no better: every read of the bases is
+				// followed by a wait for ALL LDS operations, the in-flight table reads included.)
+				constexpr int CHK = BTLBF_SPACED_CHK;
+				const uint32_t my_e = dcu[threadIdx.x & 63u];
+				auto entry = [&](uint32_t u) { return u < n_dcu ? (uint32_t)__builtin_amdgcn_readlane((int)my_e, (int)u) : 0u; };
+				auto spans = [&](const uint32_t (&e)[CHK], uint32_t (&span)[CHK]) {
+#pragma unroll
+					for (int c = 0; c < CHK; ++c) {
+						const uint32_t off = e[c] & 0xffffu;
+						if (GRP == 4) {
+							span[c] = lds_u32(bp + g0 + off);
+						} else {
+#if BTLBF_SPACED_U8
+							// two byte reads: ONE unaligned ds_read_u16 (half of these addresses are odd) made the whole
+							// kernel 45 % slower -- 136 instead of 92 ms per 6x10^9 k-mers; misaligned LDS accesses are
+							// replayed on this chip, they are not a free convenience
+							span[c] = (uint32_t)bp[g0 + off] | ((uint32_t)bp[g0 + off + 1] << 8);
+#else
+							uint16_t s2;
+							__builtin_memcpy(&s2, bp + g0 + off, 2); // (unaligned ds_read_u16)
+							span[c] = s2;
+#endif
+						}
+					}
+				};
+				auto lookups = [&](const uint32_t (&e)[CHK], const uint32_t (&span)[CHK], U64x2 (&tt)[CHK][GRP]) {
+#pragma unroll
+					for (int c = 0; c < CHK; ++c) {
+						const uint32_t row = (e[c] & 0xffffu) * (kNumCodes * 16);
+#pragma unroll
+						for (int q = 0; q < GRP; ++q)
+							tt[c][q] = tab16(pos_tab, row + ((span[c] >> (8 * q)) & kCodeOff));
+					}
+				};
+				// offsets left out by every seed: into the common base (entries past the list's end read row 0 and are
+				// masked out with a zero mask below; here they are simply not there: n_all is exact)
+				uint32_t u = 0;
+				for (; u < n_all; u += CHK) {
+					uint32_t e[CHK], span[CHK];
+					U64x2 tt[CHK][GRP];
+#pragma unroll
+					for (int c = 0; c < CHK; ++c)
+						e[c] = u + c < n_all ? entry(u + c) : 0u;
+					spans(e, span);
+					lookups(e, span, tt);
+#pragma unroll
+					for (int c = 0; c < CHK; ++c) {
+						if (u + c < n_all) {
+#pragma unroll
+							for (int q = 0; q < GRP; ++q) {
+								bf[q] ^= tt[c][q].x;
+								br[q] ^= tt[c][q].y;
+							}
+						}
+					}
+				}
+				uint64_t af[GRP][HS], ar[GRP][HS];
+#pragma unroll
+				for (int q = 0; q < GRP; ++q) {
+#pragma unroll
+					for (int j = 0; j < HS; ++j) {
+						af[q][j] = bf[q];
+						ar[q][j] = br[q];
+					}
+				}
+				for (u = n_all; u < n_dcu; u += CHK) {
+					uint32_t e[CHK], span[CHK];
+					U64x2 tt[CHK][GRP];
+#pragma unroll
+					for (int c = 0; c < CHK; ++c)
+						e[c] = entry(u + c); // (0 behind the end of the list: row 0, no seed)
+					spans(e, span);
+					lookups(e, span, tt);
+#pragma unroll
+					for (int c = 0; c < CHK; ++c) {
+						const uint32_t m = e[c] >> 16;
+#pragma unroll
+						for (int j = 0; j < HS; ++j) {
+							if ((m >> j) & 1u) {
+#pragma unroll
+								for (int q = 0; q < GRP; ++q) {
+									af[q][j] ^= tt[c][q].x;
+									ar[q][j] ^= tt[c][q].y;
+								}
+							}
+						}
+					}
+				}
+#pragma unroll
+				for (int q = 0; q < GRP; ++q) {
+					WinHash<SPACED> wh;
+					wh.kms = hp.kms;
+					wh.stn = 0;
+					// (not used by the spaced path's consumers, kept meaningful: the canonical hash of the whole window)
+					wh.bcan = 0;
+					if (hp.h2 == 1) {
+#pragma unroll
+						for (int j = 0; j < HS; ++j) {
+							const bool rev = ar[q][j] < af[q][j];
+							wh.hv[SPACED ? j : 0] = rev ? ar[q][j] : af[q][j];
+							wh.stn |= (uint32_t)rev << j;
+						}
+					} else {
+						// h2 hashes per seed: hash j*h2 is the seed's own value, hash j*h2 + j2 its j2-th extra hash
+						// (nthash.hpp:847-852).  (j, j2) run along as uniform counters; the seed's value is picked from
+						// the registers with a select chain (the index is not a compile-time constant here)
+						uint32_t j = 0, j2 = 0;
+						uint64_t b = 0;
+						bool rev = false;
+#pragma unroll
+						for (int idx = 0; idx < HS; ++idx) {
+							if (j2 == 0) {
+								uint64_t fs = 0, rs = 0;
+#pragma unroll
+								for (int jj = 0; jj < HS; ++jj) {
+									fs = j == (uint32_t)jj ? af[q][jj] : fs;
+									rs = j == (uint32_t)jj ? ar[q][jj] : rs;
+								}
+								rev = rs < fs;
+								b = rev ? rs : fs;
+							}
+							wh.hv[SPACED ? idx : 0] = j2 ? extra_hash(b, hp.kms, j2) : b;
+							wh.stn |= (uint32_t)rev << idx;
+							if (++j2 == hp.h2) {
+								j2 = 0;
+								++j;
+							}
+						}
+					}
+					f(g0 + q, okw[q], wh);
+				}
+			}
+			st.fh = fh;
+			st.rh = rh;
+			st.good = good;
+			st.first_valid = first_valid;
+			return;
+		}
+	}
 #pragma unroll
 	for (int w = W0; w < W1; ++w) {
 		if (w > 0) {

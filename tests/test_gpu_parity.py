@@ -1092,3 +1092,71 @@ def test_out_of_memory_mid_pass_gives_right_bytes_or_an_error_never_wrong_bytes(
     assert b.digest() == want
     _, _, cnt = b.containsSeqs(reads, read_len=L, want_valid=False, want_counts=True)
     assert cnt.tolist() == [n * (L - k + 1)] * 2
+
+
+@pytest.mark.parametrize("shape", ["reads_100_200", "tiny_sequences", "tile_edges", "mixed_long"])
+def test_partitioned_ragged_layout_start_bitmap(bf, shape):
+    """Ragged buffers (btlbf_layout::starts -- what the reference's FASTA loop hands over sequence by sequence,
+    Tests/AdHoc/ParallelFilter.cpp:104-122) through pass A's overlapped schedule, which marks the sequence starts of the
+    next tile in an LDS bitmap while the current tile is partitioned: many tiles per workgroup, more starts in a tile
+    than staging threads (sequences of 1..12 bases, empty ones), starts exactly on and next to tile boundaries
+    (tiles of 8192 window starts), long and short sequences mixed, an unaligned base pointer.  Bodies, hit and valid
+    bitmaps must equal the direct kernels'."""
+    import torch
+
+    bits, h, k = 1 << 32, 4, 31
+    rng = np.random.RandomState({"reads_100_200": 1, "tiny_sequences": 2, "tile_edges": 3, "mixed_long": 4}[shape])
+    total = 24_000_000  # ~ 2900 tiles: a dozen per workgroup
+    if shape == "reads_100_200":
+        lens = rng.randint(100, 201, total // 150 + 1000)
+    elif shape == "tiny_sequences":
+        total = 6_000_000
+        lens = np.concatenate([rng.randint(0, 13, 400_000), rng.randint(40, 300, 20_000)])
+        rng.shuffle(lens)
+    elif shape == "tile_edges":
+        # sequence ends placed on multiples of 8192 and one or two bases either side of them, k-1 bases before them ...
+        lens = []
+        pos = 0
+        for i in range(1, total // 8192):
+            target = i * 8192 + int(rng.choice([-31, -30, -2, -1, 0, 1, 2, 29, 30, 31]))
+            if target - pos > 0:
+                mid = pos + (target - pos) // 2
+                lens += [mid - pos, target - mid]
+                pos = target
+        lens = np.array(lens)
+    else:
+        lens = np.concatenate([rng.randint(31, 120, 100_000), rng.randint(100_000, 900_000, 20), [0, 0, 30, 31, 1]])
+        rng.shuffle(lens)
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    starts = starts[starts <= total]
+    if starts[-1] != total:
+        starts = np.concatenate([starts, [total]])
+    store = torch.zeros(total + 8, dtype=torch.uint8, device="cuda")
+    store[3:3 + total] = bf.synth_reads_device(7, 0, total // 100 + 1, 100)[:total]
+    seq = store[3:3 + total]  # a base pointer that is no multiple of four
+    seq[12345] = ord("N")
+    ts = torch.from_numpy(starts.astype(np.int64)).cuda()
+    a, b = bf.BloomFilter(bits, h, k), bf.BloomFilter(bits, h, k)
+    a.setInsertMode("direct")
+    b.setInsertMode("partitioned")
+    b.setProfiling(True)
+    a.insertSeqs(seq, starts=ts)
+    b.insertSeqs(seq, starts=ts)
+    torch.cuda.synchronize()
+    prof = b.getProfile()
+    assert prof.get("insert_hash", (0, 0))[1] >= 1 and "insert_direct" not in prof, prof
+    assert b.compare(a) == (0, 0, 0) and a.getPop() == b.getPop() > 0
+    # query: the same buffer with some foreign stretches; both modes must answer alike, window by window
+    q = seq.clone()
+    q[1_000_000:1_020_000] = bf.synth_reads_device(9, 0, 200, 100)
+    res = {}
+    for mode in ("direct", "partitioned"):
+        b.setQueryMode(mode)
+        hit, valid, cnt = b.containsSeqs(q, starts=ts, want_valid=True, want_counts=True)
+        torch.cuda.synchronize()
+        res[mode] = (hit, valid, cnt.tolist())
+    assert res["direct"][2] == res["partitioned"][2]
+    assert bool(torch.equal(res["direct"][1], res["partitioned"][1])), "valid bitmaps differ"
+    assert bool(torch.equal(res["direct"][0], res["partitioned"][0])), "hit bitmaps differ"
+    want_clean = int(np.clip(np.diff(starts) - (k - 1), 0, None).sum())
+    assert abs(res["direct"][2][0] - want_clean) <= 2 * k  # (the N and the foreign stretch's seams)
