@@ -637,7 +637,7 @@ hipError_t launch_count_per_seq(const uint64_t* hit_bits, const uint64_t* valid_
 template <bool STAGED>
 __global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, uint64_t n_reads, uint32_t L, uint32_t stride,
                                                           const HashParams hp, const ModParams mod, const void* filter,
-                                                          uint32_t counting, uint32_t threshold,
+                                                          uint32_t counting, uint32_t threshold, uint32_t probes2,
                                                           unsigned long long* flags, unsigned long long* n_cold)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t staged[]; // STAGED: 256 * L + 32 bytes
@@ -737,10 +737,17 @@ __global__ __launch_bounds__(256) void read_sample_kernel(const uint8_t* seq, ui
 		const bool c0 = hash_at(0, b0);
 		const bool c1 = W / 2 != 0 ? hash_at(W / 2, b1) : false;
 		bool h0 = true, h1 = true;
-		for (uint32_t j = 0; j < hp.h; ++j) { // both samples' probes, interleaved: 2h loads before the first use
-			const uint32_t v0 = fetch(c0 ? b0 : 0, j), v1 = fetch(c1 ? b1 : 0, j);
+		// (probes2 <= h probes of the second sample: what a present read costs is its probes -- all of them hit, so all
+		// of them are loaded --, and the second sample is only there so that a foreign read does not pass on one
+		// false-positive window; how many probes that takes depends on how many foreign reads there are: the caller
+		// works it out from its estimate)
+		for (uint32_t j = 0; j < hp.h; ++j) { // both samples' probes, interleaved: up to 2h loads before the first use
+			const uint32_t v0 = fetch(c0 ? b0 : 0, j);
 			h0 &= counting ? v0 >= threshold : v0 != 0;
-			h1 &= counting ? v1 >= threshold : v1 != 0;
+			if (j < probes2) {
+				const uint32_t v1 = fetch(c1 ? b1 : 0, j);
+				h1 &= counting ? v1 >= threshold : v1 != 0;
+			}
 		}
 		const uint32_t s0 = c0 ? (h0 ? 2u : 1u) : 0u, s1 = c1 ? (h1 ? 2u : 1u) : 0u; // 0 = unclean, 1 = miss, 2 = hit
 		uint32_t clean = (s0 != 0) + (s1 != 0), misses = (s0 == 1) + (s1 == 1);
@@ -908,23 +915,107 @@ __global__ __launch_bounds__(256) void merge_split_bitmaps_kernel(uint64_t n_wor
 		valid_out[w] = valid;
 }
 
+// Only the cold reads are gathered (the split query's masked form: the warm reads stay where they are): one thread per
+// read looks at its flag; a cold one copies its read to cold_buf[rank * L ..] in 16-byte steps and notes where it came
+// from.  (compact_reads_kernel, one thread per 16-byte piece of EVERY read, spends its time finding out that 99 % of
+// the pieces are not wanted.)
+__global__ __launch_bounds__(256) void gather_cold_reads_kernel(const uint8_t* seq, uint64_t n_reads, uint32_t L,
+                                                                const unsigned long long* flags, const uint32_t* prefix,
+                                                                uint8_t* cold_buf, uint32_t* cold_index)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads)
+		return;
+	bool cold;
+	const uint32_t rk = cold_rank(flags, prefix, r, &cold);
+	if (!cold)
+		return;
+	cold_index[rk] = (uint32_t)r;
+	const uint8_t* src = seq + r * L;
+	uint8_t* dst = cold_buf + (uint64_t)rk * L;
+	uint32_t i = 0;
+	for (; i + 16 <= L; i += 16) {
+		uint32_t w[4];
+		__builtin_memcpy(w, src + i, 16); // unaligned loads / stores
+		__builtin_memcpy(dst + i, w, 16);
+	}
+	for (; i + 4 <= L; i += 4) {
+		uint32_t w;
+		__builtin_memcpy(&w, src + i, 4);
+		__builtin_memcpy(dst + i, &w, 4);
+	}
+	for (; i < L; ++i)
+		dst[i] = src[i];
+}
+
+hipError_t launch_gather_cold_reads(const uint8_t* seq, uint64_t n_reads, uint32_t L, const uint64_t* flags,
+                                    const uint32_t* prefix, uint8_t* cold_buf, uint32_t* cold_index, hipStream_t s)
+{
+	if (n_reads == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(gather_cold_reads_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, seq, n_reads, L,
+	                   reinterpret_cast<const unsigned long long*>(flags), prefix, cold_buf, cold_index);
+	return hipGetLastError();
+}
+
+// The cold reads' answers (bitmaps over the gathered cold buffer) go back to where the reads lie in the caller's
+// buffer: one thread per cold read ORs its L bits into the caller's bitmaps, whose bits for that read pass A left zero.
+__global__ __launch_bounds__(256) void merge_cold_bitmaps_kernel(uint64_t n_cold, uint32_t L, const uint32_t* cold_index,
+                                                                 const uint64_t* cold_hit, const uint64_t* cold_valid,
+                                                                 unsigned long long* hit_out, unsigned long long* valid_out)
+{
+	const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_cold)
+		return;
+	uint64_t src = c * L, dst = (uint64_t)cold_index[c] * L;
+	for (uint32_t left = L; left;) {
+		const uint32_t sh = (uint32_t)(dst & 63), n = left < 64 - sh ? left : 64 - sh;
+		if (hit_out) {
+			const uint64_t v = bits_at(cold_hit, src, n);
+			if (v)
+				atomicOr(&hit_out[dst >> 6], (unsigned long long)(v << sh));
+		}
+		if (valid_out) {
+			const uint64_t v = bits_at(cold_valid, src, n);
+			if (v)
+				atomicOr(&valid_out[dst >> 6], (unsigned long long)(v << sh));
+		}
+		src += n;
+		dst += n;
+		left -= n;
+	}
+}
+
+hipError_t launch_merge_cold_bitmaps(uint64_t n_cold, uint32_t L, const uint32_t* cold_index, const uint64_t* cold_hit,
+                                     const uint64_t* cold_valid, uint64_t* hit_out, uint64_t* valid_out, hipStream_t s)
+{
+	if (n_cold == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(merge_cold_bitmaps_kernel, dim3((unsigned)((n_cold + 255) / 256)), dim3(256), 0, s, n_cold, L,
+	                   cold_index, cold_hit, cold_valid, reinterpret_cast<unsigned long long*>(hit_out),
+	                   reinterpret_cast<unsigned long long*>(valid_out));
+	return hipGetLastError();
+}
+
 // stride > 1: only every stride-th read is sampled and only *n_cold is produced (a cheap estimate)
 hipError_t launch_read_sample(const uint8_t* seq, uint64_t n_reads, uint32_t L, uint32_t stride, const HashParams& hp,
                               const ModParams& mod, const void* filter, int counting, uint32_t threshold, uint64_t* flags,
-                              uint64_t* n_cold, hipStream_t s)
+                              uint64_t* n_cold, hipStream_t s, uint32_t probes2)
 {
 	if (n_reads == 0 || stride == 0)
 		return hipSuccess;
+	if (probes2 == 0 || probes2 > hp.h)
+		probes2 = hp.h;
 	const uint64_t n_s = (n_reads + stride - 1) / stride;
 	const size_t staged_bytes = (size_t)256 * L + 32;
 	if (stride == 1 && staged_bytes <= 40 * 1024) { // every read looked at, and 256 of them fit the LDS (L <= 159)
 		hipLaunchKernelGGL(read_sample_kernel<true>, dim3((unsigned)((n_s + 255) / 256)), dim3(256), staged_bytes, s, seq,
-		                   n_reads, L, stride, hp, mod, filter, (uint32_t)counting, threshold,
+		                   n_reads, L, stride, hp, mod, filter, (uint32_t)counting, threshold, probes2,
 		                   reinterpret_cast<unsigned long long*>(flags), reinterpret_cast<unsigned long long*>(n_cold));
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(read_sample_kernel<false>, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, seq, n_reads, L, stride,
-	                   hp, mod, filter, (uint32_t)counting, threshold, reinterpret_cast<unsigned long long*>(flags),
+	                   hp, mod, filter, (uint32_t)counting, threshold, probes2, reinterpret_cast<unsigned long long*>(flags),
 	                   reinterpret_cast<unsigned long long*>(n_cold));
 	return hipGetLastError();
 }

@@ -1259,7 +1259,7 @@ namespace {
 
 // defined further down, next to the partitioned insert
 int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, uint8_t* valid_bits,
-                         uint64_t* counts, hipStream_t s, bool* done);
+                         uint64_t* counts, hipStream_t s, bool* done, bool defer_hit_count = false);
 int want_partitioned_query(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool* yes);
 int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t s, int* decided);
 
@@ -1734,14 +1734,11 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 	return probes >= kAutoInsertRatio * (double)f->local_bytes && probes >= 4.0e6;
 }
 
-// plan the single-GPU pipeline for a buffer and (re)allocate the scratch;
-// *ok = false means "not applicable, use the direct kernel"
-int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan& pl, PartTiling* tiling,
-                 uint8_t** extra, bool* ok, int mode, double auto_ratio)
+// the segment size and the level-0 bins (pass A's output) of this filter's local array; false = no partitioned path
+bool plan_level0(const btlbf_filter* f, PartPlan& pl)
 {
-	*ok = false;
 	if (!plan_segments(f->mod.shard_len, pl, f->kind == BTLBF_COUNTING8 ? 0 : 3))
-		return BTLBF_OK;
+		return false;
 	PartLevel& l0 = pl.lv[0];
 	if (pl.n_seg <= 1024) {
 		l0.bins = (uint32_t)pl.n_seg;
@@ -1758,10 +1755,22 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
 		l0.shift = pl.seg_shift + b1;
 		l0.bins = (uint32_t)((pl.n_seg + (1ull << b1) - 1) >> b1);
 		if (l0.shift > 32)
-			return BTLBF_OK; // (cannot happen below 2^22 segments)
+			return false; // (cannot happen below 2^22 segments)
 	}
 	l0.P = l0.bins;
 	l0.alloc_bins = l0.bins;
+	return true;
+}
+
+// plan the single-GPU pipeline for a buffer and (re)allocate the scratch;
+// *ok = false means "not applicable, use the direct kernel"
+int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan& pl, PartTiling* tiling,
+                 uint8_t** extra, bool* ok, int mode, double auto_ratio)
+{
+	*ok = false;
+	if (!plan_level0(f, pl))
+		return BTLBF_OK;
+	PartLevel& l0 = pl.lv[0];
 	l0.regions = part_hash_regions(f->hp, l0.P, cu_count(f->device)); // pass-A workgroups: one or two per CU
 	if (!plan_splits(pl, l0.regions, cu_count(f->device)) || !part_hash_fits(f->hp, l0.P))
 		return BTLBF_OK;
@@ -1900,8 +1909,10 @@ int resolve_range(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, const
 // cache-resident hash set and one more hashing pass clears the windows that own one of them.  Too
 // many failures (a miss-heavy batch) and the batch is redone by the direct gather kernel.
 // hit_bits (device) is required; valid_bits and counts are optional.
+// base.read_mask (the split query): those reads are left out -- no bits, no counts; defer_hit_count: counts[1] is left
+// for the caller, who adds the left-out reads' answers to the bitmap first.
 int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits, uint8_t* valid_bits,
-                         uint64_t* counts, hipStream_t s, bool* done)
+                         uint64_t* counts, hipStream_t s, bool* done, bool defer_hit_count)
 {
 	*done = false;
 	PartPlan pl;
@@ -1969,7 +1980,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 		d.gate_mode = GATE_RESOLVE;
 		HIP_TRY(launch_seq_op(OP_BF_RESOLVE, d, s));
 	}
-	if (counts) // hits = set bits of the final bitmap
+	if (counts && !defer_hit_count) // hits = set bits of the final bitmap
 		HIP_TRY(launch_popcount(hit_bits, ((base.len + 63) / 64) * 8, 0, 0,
 		                        reinterpret_cast<unsigned long long*>(counts) + 1, s));
 	*done = true;
@@ -2058,19 +2069,20 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 		*have = bytes;
 		return true;
 	};
-	const uint64_t sz_flags = up(n_fw * 8 + 8), sz_prefix = up((n_fw + (n_fw + 1023) / 1024 + 1) * 4);
+	// (the flags are readable for 256 bytes behind their last word: pass A reads up to 34 words from a tile's first one on)
+	const uint64_t sz_flags = up(n_fw * 8 + 256), sz_prefix = up((n_fw + (n_fw + 1023) / 1024 + 1) * 4);
 	if (!grow(&f->d_flags, &f->flags_bytes, 256 + sz_flags + sz_prefix))
 		return BTLBF_OK; // no room: the plain paths decide (want_partitioned_query)
 	unsigned long long* d_ncold = static_cast<unsigned long long*>(f->d_flags);
 	uint64_t* d_flags = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(f->d_flags) + 256);
 	uint32_t* d_prefix = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(f->d_flags) + 256 + sz_flags);
 	unsigned long long n_cold = 0;
-	auto sample = [&](uint32_t stride) -> int {
+	auto sample = [&](uint32_t stride, uint32_t probes2) -> int {
 		HIP_TRY(hipMemsetAsync(d_ncold, 0, 8, s));
 		{
 			ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
 			HIP_TRY(launch_read_sample(a.seq, n_reads, L, stride, f->hp, f->mod, f->d_data, f->kind == BTLBF_COUNTING8,
-			                           f->thr, d_flags, reinterpret_cast<uint64_t*>(d_ncold), s));
+			                           f->thr, d_flags, reinterpret_cast<uint64_t*>(d_ncold), s, probes2));
 		}
 		HIP_TRY(hipMemcpyAsync(&n_cold, d_ncold, 8, hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
@@ -2087,9 +2099,11 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 	//    1/64 of the cost of looking at every read
 	int rc;
 	const uint32_t stride = n_reads >= (1u << 20) ? 64 : 1;
+	double cold_frac = 1.0; // estimate from the first look (unknown: assume many)
 	if (stride > 1) {
-		if ((rc = sample(stride)))
+		if ((rc = sample(stride, 0)))
 			return rc;
+		cold_frac = (double)n_cold / (double)((n_reads + stride - 1) / stride);
 		const uint64_t n_s = (n_reads + stride - 1) / stride;
 		if (n_cold == 0 && (double)n_reads * 8.0 / (double)n_s < few_cold) { // none in the sample: few overall
 			*decided = 2;
@@ -2100,8 +2114,12 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 			return BTLBF_OK;
 		}
 	}
-	// 2. every read
-	if ((rc = sample(1)))
+	// 2. every read.  A present read costs the sampler its probes (they all hit, so they are all loaded), and the second
+	//    sample only has to keep a foreign read from passing on ONE false-positive window: with few foreign reads, fewer
+	//    of its probes do (a read that passes all the same costs a resolve pass, never a wrong answer)
+	const uint32_t h = f->hp.h;
+	const uint32_t probes2 = cold_frac <= 0.0025 ? (h + 1) / 2 : cold_frac <= 0.025 ? std::max((h + 1) / 2, h - 1) : h;
+	if ((rc = sample(1, probes2)))
 		return rc;
 	const uint64_t n_warm = n_reads - n_cold;
 	if ((double)n_cold < few_cold) { // the fail list copes with that many misses
@@ -2115,6 +2133,89 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 	// ---- split ----
 	const uint64_t warm_len = n_warm * L, cold_len = n_cold * L;
 	const bool wv = a.valid_bits != nullptr;
+	// Uniform reads that pass A takes through its read grid: the warm reads stay where they are -- pass A leaves the
+	// cold ones out by their flags (zero-staged: no entries, no bits, no counts) --, only the COLD reads are gathered for
+	// the direct kernel, and their answers are ORed back into the caller's bitmaps.  The first version gathered the warm
+	// reads as well (15 GB copied and 15 GB of HBM that the partition scratch then lacked: a third batch) and merged
+	// every word of the bitmaps from two sources.
+	{
+		PartPlan pl0;
+		PartGrid g;
+		// (up to a quarter of the reads cold: beyond that the lanes pass A spends on zero-staged reads cost more than
+		// gathering the warm reads costs -- at one read in two 76 instead of 43 ms of pass A per 10^8 reads)
+		if (4 * n_cold <= n_reads && plan_level0(f, pl0) && part_read_grid(f->hp, pl0.lv[0].P, a.layout, &g)) {
+			const uint64_t szm[5] = {up(cold_len + 16), up(bitmap_bytes(cold_len) + 16), wv ? up(bitmap_bytes(cold_len) + 16) : 0,
+			                         up(n_cold * 4 + 16), a.hit_bits ? 0 : up(bitmap_bytes(a.len) + 16)};
+			uint64_t need = 0;
+			for (uint64_t v : szm)
+				need += v;
+			// (a buffer left behind by a call that gathered the warm reads as well -- 19 GB for 10^8 reads -- is given back
+			// first: the partition scratch is planned from the free HBM, and with that much less of it the pass would need
+			// a third batch, i.e. a third sweep of the array)
+			if (f->split_bytes > 4 * need + (1ull << 30)) {
+				(void)hipFree(f->d_split);
+				f->d_split = nullptr;
+				f->split_bytes = 0;
+			}
+			if (!grow(&f->d_split, &f->split_bytes, need)) {
+				*decided = 1;
+				return BTLBF_OK;
+			}
+			uint8_t* q[5];
+			{
+				uint64_t off = 0;
+				for (int i = 0; i < 5; ++i) {
+					q[i] = szm[i] ? static_cast<uint8_t*>(f->d_split) + off : nullptr;
+					off += szm[i];
+				}
+			}
+			uint8_t *cold_p = q[0], *cold_hit_p = q[1], *cold_valid_p = q[2];
+			uint32_t* cold_index = reinterpret_cast<uint32_t*>(q[3]);
+			uint8_t* hb = a.hit_bits ? a.hit_bits : q[4];
+			{
+				ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
+				HIP_TRY(launch_flag_prefix(d_flags, n_reads, d_prefix, s));
+				HIP_TRY(launch_gather_cold_reads(a.seq, n_reads, L, d_flags, d_prefix, cold_p, cold_index, s));
+				HIP_TRY(hipMemsetAsync(cold_hit_p + bitmap_bytes(cold_len), 0, 16, s)); // (the merge reads a word further)
+				if (wv)
+					HIP_TRY(hipMemsetAsync(cold_valid_p + bitmap_bytes(cold_len), 0, 16, s));
+			}
+			SeqArgs b = a;
+			b.read_mask = reinterpret_cast<const uint32_t*>(d_flags);
+			b.hit_bits = b.valid_bits = nullptr;
+			b.counts = nullptr;
+			bool done_w = false;
+			if ((rc = partitioned_contains(f, b, hb, a.valid_bits, a.counts, s, &done_w, true)))
+				return rc;
+			if (!done_w) { // no room for the partition scratch: the gather kernel answers the whole buffer
+				*decided = 1;
+				return BTLBF_OK;
+			}
+			SeqArgs d = a;
+			d.seq = cold_p;
+			d.len = cold_len;
+			d.hit_bits = cold_hit_p;
+			d.valid_bits = cold_valid_p;
+			d.counts = a.counts; // the direct kernel ADDS its clean windows (and its hits: recounted below)
+			{
+				ProfSpan ps(f, BTLBF_PROF_QUERY_DIRECT, s);
+				REQUIRE_MATERIALIZED(f);
+				HIP_TRY(launch_seq_op(direct_op, d, s));
+			}
+			{
+				ProfSpan ps(f, BTLBF_PROF_QUERY_RESOLVE, s);
+				HIP_TRY(launch_merge_cold_bitmaps(n_cold, L, cold_index, reinterpret_cast<const uint64_t*>(cold_hit_p),
+				                                  reinterpret_cast<const uint64_t*>(cold_valid_p), reinterpret_cast<uint64_t*>(hb),
+				                                  reinterpret_cast<uint64_t*>(a.valid_bits), s));
+				if (a.counts) { // hits = set bits of the finished bitmap
+					HIP_TRY(hipMemsetAsync(a.counts + 1, 0, 8, s));
+					HIP_TRY(launch_popcount(hb, bitmap_bytes(a.len), 0, 0, reinterpret_cast<unsigned long long*>(a.counts) + 1, s));
+				}
+			}
+			*decided = 3;
+			return BTLBF_OK;
+		}
+	}
 	const uint64_t sz[6] = {up(warm_len + 16), up(cold_len + 16), up(bitmap_bytes(warm_len) + 16),
 	                        up(bitmap_bytes(cold_len) + 16), wv ? up(bitmap_bytes(warm_len) + 16) : 0,
 	                        wv ? up(bitmap_bytes(cold_len) + 16) : 0};

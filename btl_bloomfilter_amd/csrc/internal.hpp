@@ -148,6 +148,9 @@ struct SeqArgs {
 	// staging waves mark the sequence starts of the NEXT tile while the current one is partitioned (0: none -- the
 	// starts are marked after the staging, between two more barriers per tile)
 	uint32_t sb_words;
+	// reads to leave out (the split query, uniform reads through pass A's read grid only): bit r of this device array
+	// of 32-bit words = read r of the buffer is answered elsewhere; readable for 160 bytes behind its last word
+	const uint32_t* read_mask;
 };
 
 // How pass A cuts a buffer into tiles (partition_kernels.hip: part_tiling).  All host-side planning is in
@@ -262,10 +265,14 @@ hipError_t launch_and_answers(const uint64_t* tags, const uint8_t* answers, uint
 // split query (aux_kernels.hip): per-read sampling, cold-read ranks, compaction, bitmap merge
 hipError_t launch_read_sample(const uint8_t* seq, uint64_t n_reads, uint32_t L, uint32_t stride, const HashParams& hp,
                               const ModParams& mod, const void* filter, int counting, uint32_t threshold, uint64_t* flags,
-                              uint64_t* n_cold, hipStream_t s);
+                              uint64_t* n_cold, hipStream_t s, uint32_t probes2 = 0);
 hipError_t launch_flag_prefix(const uint64_t* flags, uint64_t n_reads, uint32_t* prefix, hipStream_t s);
 hipError_t launch_compact_reads(const uint8_t* seq, uint64_t n_reads, uint32_t L, const uint64_t* flags,
                                 const uint32_t* prefix, uint8_t* warm_buf, uint8_t* cold_buf, hipStream_t s);
+hipError_t launch_gather_cold_reads(const uint8_t* seq, uint64_t n_reads, uint32_t L, const uint64_t* flags,
+                                    const uint32_t* prefix, uint8_t* cold_buf, uint32_t* cold_index, hipStream_t s);
+hipError_t launch_merge_cold_bitmaps(uint64_t n_cold, uint32_t L, const uint32_t* cold_index, const uint64_t* cold_hit,
+                                     const uint64_t* cold_valid, uint64_t* hit_out, uint64_t* valid_out, hipStream_t s);
 hipError_t launch_merge_split_bitmaps(uint64_t len, uint32_t L, const uint64_t* flags, const uint32_t* prefix,
                                       const uint64_t* warm_hit, const uint64_t* cold_hit, const uint64_t* warm_valid,
                                       const uint64_t* cold_valid, uint64_t* hit_out, uint64_t* valid_out, hipStream_t s);

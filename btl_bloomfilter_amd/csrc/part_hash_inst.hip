@@ -103,7 +103,10 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 		// in flight while this one is hashed and partitioned
 		uint32_t mis = 0;
 		if (grid) {
-			seq_stage_convert_grid<NT, kPartW>(raw, tile, sh, a.seq, a.len, L, a.rg_lpad, tile_bytes, g0);
+			// (a read mask is looked up in global memory here: this schedule stages at the top of the tile, in front of
+			// the partition rounds' stores)
+			seq_stage_convert_grid<NT, kPartW>(raw, tile, sh, a.seq, a.len, L, a.rg_lpad, tile_bytes, g0, -1, a.read_mask,
+			                                   (uint32_t)(t * a.rg_reads));
 			STAMP(1); // conversion of this thread's words
 			__syncthreads();
 		} else {
@@ -237,7 +240,11 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 // schedule (bit-identical filters: tests/test_gpu_parity.py, tools/fuzz_parity.py).
 static constexpr int kOvOwners = 8;
 
-template <int H, bool POW2, bool SPACED, bool QUERY, bool WINDOW>
+// AUX: the instantiation that knows the ragged layout's start bitmap and the split query's read mask.  Both cost
+// registers in the tile loop whether a launch uses them or not (the kernel sits at its 128 with nothing to spare: with
+// them compiled in, the variants for filters of no power-of-two size went from 16 to 60 bytes of scratch per lane and
+// from 57.7 to 62.6 ms per launch), so launches that use neither take the instantiation without.
+template <int H, bool POW2, bool SPACED, bool QUERY, bool WINDOW, bool AUX>
 __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const SeqArgs a, const PartOut out,
                                                                       const uint32_t bin_shift, const PartSide sd)
 {
@@ -259,8 +266,14 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	uint8_t* tile = dyn;
 	// ragged layout: one bit per staged byte of the NEXT tile, set where a sequence starts (see `mark_ahead` below)
 	uint32_t* const sbm = reinterpret_cast<uint32_t*>(dyn + tile_cap);
-	const bool sb = a.sb_words != 0;
+	const bool sb = AUX && a.sb_words != 0;
 	__shared__ uint32_t sb_cnt; // starts of the tile being marked that lie at or before the start of the one after it
+	// split query: the read-mask words that cover the reads of the tile being staged (a tile holds at most 1024 reads,
+	// which begin anywhere in a word), fetched by the first staging threads together with the tile's words and handed
+	// over through here
+	__shared__ uint32_t rmask[36];
+	const bool masked = AUX && a.read_mask != nullptr && grid;
+	const uint32_t n_mw = masked ? (a.rg_reads + 62) / 32 : 0; // <= 34
 	uint8_t* spaced_lds = dyn + tile_cap + a.sb_words * 4;
 	const PartLds pl = part_carve(spaced_lds + seq_spaced_bytes(a.hp), out.P);
 	part_init<kPartThreads>(pl, out.P);
@@ -315,7 +328,8 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	auto stage_convert = [&](uint64_t t) {
 		const uint64_t g0 = t * (uint64_t)tile_bytes;
 		if (grid)
-			seq_stage_convert_grid<NY, kStageKW>(raw, tile, sh, a.seq, a.len, L, a.rg_lpad, tile_bytes, g0, ytid);
+			seq_stage_convert_grid<NY, kStageKW>(raw, tile, sh, a.seq, a.len, L, a.rg_lpad, tile_bytes, g0, ytid,
+			                                     masked ? rmask : nullptr, (uint32_t)(t * a.rg_reads) & 31u);
 		else
 			seq_stage_convert<NY, kStageKW, false, false, true>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off,
 			                                                    span, ytid, sb && t != t_begin ? sbm : nullptr);
@@ -372,6 +386,8 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 		__syncthreads();
 	};
 
+	if (tid < n_mw && t_begin < t_end)
+		rmask[tid] = a.read_mask[((t_begin * a.rg_reads) >> 5) + tid];
 	__syncthreads(); // tables and partition state ready (and the grid's zeroed image)
 	if (t_begin < t_end) {
 		if (isY) {
@@ -515,6 +531,7 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 				sb_cnt = 0;
 		}
 		uint64_t sp_mine = ~0ull, sp_last = ~0ull;
+		uint32_t mask_word = 0;
 		// (unrolled: with one rolled copy of the round the register allocator spills inside the loop)
 #pragma unroll
 		for (uint32_t r = 0; r < 2; ++r) {
@@ -528,6 +545,8 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 				// memory operation pending" in front of the loads would also wait for the stores of late entries,
 				// and the X waves would find the Y waves still there when they arrive at the barrier
 				stage_request(t + 1);
+				if ((uint32_t)ytid < n_mw)
+					mask_word = a.read_mask[(((t + 1) * a.rg_reads) >> 5) + (uint32_t)ytid];
 				if (sb) {
 					if (t == t_begin) { // (uniform: kept in scalar registers)
 						const uint64_t v = sh.start_lo;
@@ -541,6 +560,8 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			part_round_p1_late<E, WINDOW ? 1 : H, WINDOW>(pl, bin, val, live, late0 + (uint64_t)r * sd.late_cap, ovf);
 			if (sb && r == 1 && isY && t + 1 < t_end)
 				mark_ahead(t + 1, sp_mine, sp_last);
+			if (r == 1 && isY && t + 1 < t_end && (uint32_t)ytid < n_mw)
+				rmask[ytid] = mask_word; // read by the conversion behind the barrier
 			OV_STAMP(0);
 			__syncthreads(); // (round 1: nobody reads this tile's image any more)
 			OV_STAMP(1);
@@ -640,17 +661,27 @@ static hipError_t launch_hash_h(const SeqArgs& a, const PartOut& out, uint32_t b
 #else
 	constexpr bool kOvSpaced = false;
 #endif
+	const bool aux = a.sb_words != 0 || (a.read_mask != nullptr && a.rg_reads != 0); // (see part_hash_ov_kernel)
 	const bool overlapped = !SMALL && kOvH && (!spaced || kOvSpaced) && out.P <= 64u * kOvOwners && !ov_off && sd.late_buf != nullptr &&
 	                        sd.late_cap >= kStageEntries;
 #define BTLBF_PLAUNCH(P, S, W)                                                                                      \
 	do {                                                                                                            \
 		if constexpr (!SMALL && (!S || kOvSpaced) && kOvH) {                                                        \
-			if (overlapped) {                                                                                       \
-				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, S, Q, W>), \
+			if (overlapped && aux) {                                                                                \
+				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, S, Q, W, true>), \
 				                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);            \
 				if (e != hipSuccess)                                                                                \
 					return e;                                                                                       \
-				hipLaunchKernelGGL((part_hash_ov_kernel<H, P, S, Q, W>), dim3(out.regions), dim3(NT), dyn, s, a, out, \
+				hipLaunchKernelGGL((part_hash_ov_kernel<H, P, S, Q, W, true>), dim3(out.regions), dim3(NT), dyn, s, a, out, \
+				                   bin_shift, sd);                                                                  \
+				break;                                                                                              \
+			}                                                                                                       \
+			if (overlapped) {                                                                                       \
+				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&part_hash_ov_kernel<H, P, S, Q, W, false>), \
+				                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);            \
+				if (e != hipSuccess)                                                                                \
+					return e;                                                                                       \
+				hipLaunchKernelGGL((part_hash_ov_kernel<H, P, S, Q, W, false>), dim3(out.regions), dim3(NT), dyn, s, a, out, \
 				                   bin_shift, sd);                                                                  \
 				break;                                                                                              \
 			}                                                                                                       \

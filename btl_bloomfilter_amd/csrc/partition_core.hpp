@@ -15,7 +15,7 @@ static constexpr int kPartHalf = 4;                     // ... partitioned in tw
 static constexpr int kPartTile = kPartThreads * kPartW; // windows per tile of pass A
 static constexpr uint32_t kStageEntries = 32768; // LDS staging: 128 KiB of uint32 entries
 static constexpr uint32_t kFlushItems = kStageEntries / kChunk; // chunks the rings can hold = most one round flushes
-static constexpr uint32_t kPartLdsBudget = 160 * 1024 - 1536; // dynamic LDS a workgroup may ask for (static: SeqShared)
+static constexpr uint32_t kPartLdsBudget = 160 * 1024 - 1664; // dynamic LDS a workgroup may ask for (static: SeqShared + the overlapped schedule's handover words, 1600 bytes)
 
 // LDS image of the staged partitioner (carved from dynamic LDS by the kernels)
 struct PartLds {

@@ -313,11 +313,19 @@ __device__ __forceinline__ uint32_t seq_stage_convert(const StageRaw<KW>& pre, u
 // and the pad bytes between reads (zeroed once by the kernel, never written) end every window that would run
 // over a read's end.  Same staged byte as seq_stage_convert (code << 4 | valid | good, `good` cleared on a
 // read's first base).  The caller provides the barriers.
+// skip_bits != nullptr: bit (skip_bit0 + q) of that array (32-bit words, LDS or global) says that read q of the tile
+// is to be LEFT OUT (the split query's cold reads, which another kernel answers): its bytes are staged as zeros, so
+// none of its windows is clean -- no entries, no bits in the bitmaps, nothing counted.
 template <int NT, int KW>
 __device__ __forceinline__ void seq_stage_convert_grid(const StageRaw<KW>& pre, uint8_t* tile, SeqShared& sh,
                                                        const uint8_t* seq, uint64_t len, uint32_t L, uint32_t lpad,
-                                                       uint32_t tile_bytes, uint64_t g0, int32_t tid_in = -1)
+                                                       uint32_t tile_bytes, uint64_t g0, int32_t tid_in = -1,
+                                                       const uint32_t* skip_bits = nullptr, uint32_t skip_bit0 = 0)
 {
+	auto skipped = [&](uint32_t q) -> bool {
+		const uint32_t b = skip_bit0 + q;
+		return (skip_bits[b >> 5] >> (b & 31)) & 1u;
+	};
 	uint32_t tid = tid_in < 0 ? threadIdx.x : (uint32_t)tid_in; // laundered: see seq_stage_convert
 	asm volatile("" : "+v"(tid));
 	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(seq + g0) & 3);
@@ -354,6 +362,8 @@ __device__ __forceinline__ void seq_stage_convert_grid(const StageRaw<KW>& pre, 
 			uint32_t h0 = o & 0xffffu, h1 = o >> 16;
 			if (p == 0)
 				h0 &= ~kBaseGood;
+			if (skip_bits && skipped(q))
+				h0 = 0;
 			*reinterpret_cast<uint16_t*>(tile + dst) = (uint16_t)h0;
 			p += 2;
 			dst += 2;
@@ -361,7 +371,10 @@ __device__ __forceinline__ void seq_stage_convert_grid(const StageRaw<KW>& pre, 
 				p = 0;
 				dst += lpad - L;
 				h1 &= ~kBaseGood;
+				++q;
 			}
+			if (skip_bits && skipped(q))
+				h1 = 0;
 			*reinterpret_cast<uint16_t*>(tile + dst) = (uint16_t)h1;
 		} else {
 #pragma unroll
@@ -372,12 +385,15 @@ __device__ __forceinline__ void seq_stage_convert_grid(const StageRaw<KW>& pre, 
 				uint32_t e = (o >> (8 * b)) & 0xffu;
 				if (p == 0)
 					e &= ~kBaseGood;
+				if (skip_bits && skipped(q))
+					e = 0;
 				tile[dst] = (uint8_t)e;
 				++p;
 				++dst;
 				if (p == L) {
 					p = 0;
 					dst += lpad - L;
+					++q;
 				}
 			}
 		}
