@@ -49,24 +49,32 @@ __device__ __forceinline__ uint64_t extra_hash(uint64_t b, uint64_t kms, uint32_
 
 // hash % size without a 64-bit divide: q = mulhi(hash, floor(2^64/size)) is the true quotient
 // or one less, so a single conditional subtract finishes (size >= 2).
+// A filter of 2^32 positions or more -- every filter the partitioned pipeline is worth it for -- has a magic
+// below 2^32, and so a quotient below 2^32: mulhi(hash, magic) is then two 32-bit multiplies instead of four, and
+// q * size a 32 x 64-bit product (same q, same remainder).  A 400-Gbit filter of no power-of-two size ran pass A at
+// 75 ms per 6x10^9 k-mers with the generic form, against 42 for 2^38 / 2^39 bits.
+__device__ __forceinline__ bool mod_small_magic(const ModParams& m) { return (uint32_t)(m.magic >> 32) == 0; }
+__device__ __forceinline__ uint64_t reduce_mod_small(uint64_t hash, const ModParams& m)
+{
+	const uint32_t mg = (uint32_t)m.magic, lo = (uint32_t)hash, hi = (uint32_t)(hash >> 32);
+	const uint32_t q = (uint32_t)(((uint64_t)hi * mg + __umulhi(lo, mg)) >> 32);
+	const uint64_t r = hash - ((uint64_t)q * (uint32_t)m.size + ((uint64_t)(q * (uint32_t)(m.size >> 32)) << 32));
+	return r >= m.size ? r - m.size : r;
+}
+__device__ __forceinline__ uint64_t reduce_mod_big(uint64_t hash, const ModParams& m)
+{
+	const uint64_t q = __umul64hi(hash, m.magic);
+	const uint64_t r = hash - q * m.size;
+	return r >= m.size ? r - m.size : r;
+}
+// (callers with many probes in a row test mod_small_magic() once and call the form they need: with the test inside,
+// the compiler keeps it -- a scalar branch and a handful of register moves per probe)
 template <bool POW2>
 __device__ __forceinline__ uint64_t reduce_mod(uint64_t hash, const ModParams& m)
 {
 	if (POW2)
 		return hash & m.mask;
-	// A filter of 2^32 positions or more -- every filter the partitioned pipeline is worth it for -- has a magic
-	// below 2^32, and so a quotient below 2^32: mulhi(hash, magic) is then two 32-bit multiplies instead of four, and
-	// q * size a 32 x 64-bit product.  (Same q, same remainder; the branch is uniform.)  A 400-Gbit filter of no
-	// power-of-two size ran pass A at 75 ms per 6x10^9 k-mers with the generic form, against 42 for 2^38 / 2^39 bits.
-	if ((uint32_t)(m.magic >> 32) == 0) {
-		const uint32_t mg = (uint32_t)m.magic, lo = (uint32_t)hash, hi = (uint32_t)(hash >> 32);
-		const uint32_t q = (uint32_t)(((uint64_t)hi * mg + __umulhi(lo, mg)) >> 32);
-		const uint64_t r = hash - ((uint64_t)q * (uint32_t)m.size + ((uint64_t)(q * (uint32_t)(m.size >> 32)) << 32));
-		return r >= m.size ? r - m.size : r;
-	}
-	uint64_t q = __umul64hi(hash, m.magic);
-	uint64_t r = hash - q * m.size;
-	return r >= m.size ? r - m.size : r;
+	return mod_small_magic(m) ? reduce_mod_small(hash, m) : reduce_mod_big(hash, m);
 }
 
 // ---- bit filter probes: bit (p%8) of byte p/8 == bit (p%32) of little-endian word p/32 --------

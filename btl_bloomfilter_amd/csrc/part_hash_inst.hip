@@ -144,22 +144,31 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 				live = 0;
 			if (!WINDOW)
 				live |= (uint32_t)ok << w4;
+			// (no power of two: the form of the reduction is picked once per window, not once per probe)
+			auto probes = [&](auto&& position) {
 #pragma unroll
-			for (int i = 0; i < H; ++i) {
-				if (POW2 && !WINDOW) {
-					const uint64_t hv = wh.at(i);
-					bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
-					val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
-					continue;
+				for (int i = 0; i < H; ++i) {
+					if (POW2 && !WINDOW) {
+						const uint64_t hv = wh.at(i);
+						bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
+						val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
+						continue;
+					}
+					uint64_t p = position(wh.at(i));
+					if (WINDOW) {
+						p -= a.mod.shard_lo;
+						live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
+					}
+					bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
+					val[w4 * H + i] = (uint32_t)p & ent_mask;
 				}
-				uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
-				if (WINDOW) {
-					p -= a.mod.shard_lo;
-					live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
-				}
-				bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
-				val[w4 * H + i] = (uint32_t)p & ent_mask;
-			}
+			};
+			if (POW2)
+				probes([&](uint64_t hv) { return hv & a.mod.mask; });
+			else if (mod_small_magic(a.mod))
+				probes([&](uint64_t hv) { return reduce_mod_small(hv, a.mod); });
+			else
+				probes([&](uint64_t hv) { return reduce_mod_big(hv, a.mod); });
 			if (w4 == kWpr - 1) {
 				STAMP(2);
 				if (SMALL) {
@@ -444,22 +453,31 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			live = 0;
 		if (!WINDOW)
 			live |= (uint32_t)ok << w4;
+		// (no power of two: the form of the reduction is picked once per window, not once per probe)
+		auto probes = [&](auto&& position) {
 #pragma unroll
-		for (int i = 0; i < H; ++i) {
-			if (POW2 && !WINDOW) {
-				const uint64_t hv = wh.at(i);
-				bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
-				val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
-				continue;
+			for (int i = 0; i < H; ++i) {
+				if (POW2 && !WINDOW) {
+					const uint64_t hv = wh.at(i);
+					bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
+					val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
+					continue;
+				}
+				uint64_t p = position(wh.at(i));
+				if (WINDOW) {
+					p -= a.mod.shard_lo;
+					live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
+				}
+				bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
+				val[w4 * H + i] = (uint32_t)p & ent_mask;
 			}
-			uint64_t p = reduce_mod<POW2>(wh.at(i), a.mod);
-			if (WINDOW) {
-				p -= a.mod.shard_lo;
-				live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
-			}
-			bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
-			val[w4 * H + i] = (uint32_t)p & ent_mask;
-		}
+		};
+		if (POW2)
+			probes([&](uint64_t hv) { return hv & a.mod.mask; });
+		else if (mod_small_magic(a.mod))
+			probes([&](uint64_t hv) { return reduce_mod_small(hv, a.mod); });
+		else
+			probes([&](uint64_t hv) { return reduce_mod_big(hv, a.mod); });
 	};
 	auto hash_lo = [&]() { seq_lane_range<SPACED, kPartW, H, 0, kPartHalf>(tile, sh, a.hp, spaced_lds, li0, st, on_window); };
 	auto hash_hi = [&]() { seq_lane_range<SPACED, kPartW, H, kPartHalf, kPartW>(tile, sh, a.hp, spaced_lds, li0, st, on_window); };
