@@ -488,9 +488,18 @@ int build_spaced(HashParams& hp, const char* const* seeds, unsigned n_seeds, uns
 			if (kv.second == all)
 				dcu.push_back(kv.first | (kv.second << 16));
 		hp.n_dcu_all = (uint32_t)dcu.size();
+		// the others grouped by their mask, every group an even number of entries: the hash stage takes them in pairs
+		// with one mask (seq_core.hpp); the filler is the "offset" k, the zero row behind the positional table
+		std::map<uint32_t, std::vector<unsigned>> by_mask;
 		for (const auto& kv : mask_of)
 			if (kv.second != all)
-				dcu.push_back(kv.first | (kv.second << 16));
+				by_mask[kv.second].push_back(kv.first);
+		for (const auto& g : by_mask) {
+			for (unsigned off : g.second)
+				dcu.push_back(off | (g.first << 16));
+			if (g.second.size() % 2)
+				dcu.push_back(k | (g.first << 16));
+		}
 		if (dcu.size() > kMaxDcu) {
 			dcu.clear();
 			hp.n_dcu_all = 0;

@@ -67,9 +67,11 @@ __host__ __device__ inline uint32_t seq_tile_cap(uint32_t tile_windows, uint32_t
 // bytes of dynamic LDS for the tables that follow the tile: the positional seed table
 // pos_tab[i*8+c] = {srol^(k-1-i)(fwd[c]), srol^i(rev[c])} (when hp.use_pos_tab) and the spaced seeds'
 // don't-care index list
+// (+ one row of zeros behind the k rows: spaced seeds pad their offset list with the "offset" k, whose terms change
+// nothing)
 __host__ __device__ inline uint32_t seq_pos_tab_bytes(const HashParams& hp)
 {
-	return hp.use_pos_tab ? hp.k * kNumCodes * 16 : 0;
+	return hp.use_pos_tab ? (hp.k + 1) * kNumCodes * 16 : 0;
 }
 __host__ __device__ inline uint32_t seq_dc_list_bytes(const HashParams& hp)
 {
@@ -103,9 +105,9 @@ __device__ __forceinline__ void seq_setup_tables(SeqShared& sh, const HashParams
 		// fwd[c] = init_tab[c][0], rev[c] = out_tab[c][1] (internal.hpp)
 		const uint32_t k = hp.k;
 		U64x2* pt = reinterpret_cast<U64x2*>(spaced_lds);
-		for (uint32_t i = tid; i < k * kNumCodes; i += NT) {
+		for (uint32_t i = tid; i < (k + 1) * kNumCodes; i += NT) {
 			const uint32_t pos = i / kNumCodes, c = i % kNumCodes;
-			pt[i] = U64x2{srol_n(hp.init_tab[c][0], k - 1 - pos), srol_n(hp.out_tab[c][1], pos)};
+			pt[i] = pos < k ? U64x2{srol_n(hp.init_tab[c][0], k - 1 - pos), srol_n(hp.out_tab[c][1], pos)} : U64x2{0, 0};
 		}
 	}
 	if (SPACED) {
@@ -647,25 +649,31 @@ __device__ __forceinline__ void seq_lane_range(const uint8_t* tile, const SeqSha
 						ar[q][j] = br[q];
 					}
 				}
-				for (u = n_all; u < n_dcu; u += CHK) {
+				// the rest of the list comes in PAIRS of offsets that the same seeds leave out (the host groups the offsets by
+				// their mask and pads a group of odd size with the zero row): the pair's two terms are XORed together first
+				// and the sum goes into the seeds of the mask -- one set of scalar branches per pair, and for a mask of n
+				// seeds 1 + n XORs of a term instead of 2n
+				static_assert(CHK == 2, "offsets are paired by mask");
+				for (u = n_all; u < n_dcu; u += 2) {
 					uint32_t e[CHK], span[CHK];
 					U64x2 tt[CHK][GRP];
-#pragma unroll
-					for (int c = 0; c < CHK; ++c)
-						e[c] = entry(u + c); // (0 behind the end of the list: row 0, no seed)
+					e[0] = entry(u);
+					e[1] = entry(u + 1);
 					spans(e, span);
 					lookups(e, span, tt);
+					const uint32_t m = e[0] >> 16;
 #pragma unroll
-					for (int c = 0; c < CHK; ++c) {
-						const uint32_t m = e[c] >> 16;
+					for (int q = 0; q < GRP; ++q) {
+						tt[0][q].x ^= tt[1][q].x;
+						tt[0][q].y ^= tt[1][q].y;
+					}
 #pragma unroll
-						for (int j = 0; j < HS; ++j) {
-							if ((m >> j) & 1u) {
+					for (int j = 0; j < HS; ++j) {
+						if ((m >> j) & 1u) {
 #pragma unroll
-								for (int q = 0; q < GRP; ++q) {
-									af[q][j] ^= tt[c][q].x;
-									ar[q][j] ^= tt[c][q].y;
-								}
+							for (int q = 0; q < GRP; ++q) {
+								af[q][j] ^= tt[0][q].x;
+								ar[q][j] ^= tt[0][q].y;
 							}
 						}
 					}
