@@ -594,7 +594,12 @@ __device__ __forceinline__ void seq_lane_range(const uint8_t* tile, const SeqSha
 					for (int c = 0; c < CHK; ++c) {
 						const uint32_t off = e[c] & 0xffffu;
 						if (GRP == 4) {
+#if BTLBF_SPACED_U8
+							span[c] = (uint32_t)bp[g0 + off] | ((uint32_t)bp[g0 + off + 1] << 8) | ((uint32_t)bp[g0 + off + 2] << 16) |
+							          ((uint32_t)bp[g0 + off + 3] << 24);
+#else
 							span[c] = lds_u32(bp + g0 + off);
+#endif
 						} else {
 #if BTLBF_SPACED_U8
 							// two byte reads: ONE unaligned ds_read_u16 (half of these addresses are odd) made the whole

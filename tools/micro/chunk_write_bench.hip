@@ -27,7 +27,10 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 	return x ^ (x >> 16);
 }
 
-template <int CB>
+// LAYOUT 0: region (reg, wg) at (reg * n_wg + wg) * cap -- the writers' regions of one bin lie together (what passes A
+// and B do: the reader of a bin finds its regions in one piece); LAYOUT 1: (wg * 1024 + reg) * cap -- a writer's 1024
+// streams lie together in one area of 1024 * cap * CB bytes (fewer pages under each workgroup's stores)
+template <int CB, int LAYOUT = 0>
 __global__ __launch_bounds__(1024) void chunk_kernel(const uint4* __restrict__ in, uint8_t* __restrict__ out, uint32_t cap,
                                                      uint32_t rounds, uint32_t n_wg)
 {
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(1024) void chunk_kernel(const uint4* __restrict__ i
 			c = __shfl(c, (int)((tid & 63) & ~7u));
 			if (c >= cap)
 				continue;
-			uint8_t* p = out + ((uint64_t)(reg * n_wg + wg) * cap + c) * CB;
+			uint8_t* p = out + ((uint64_t)(LAYOUT ? wg * 1024 + reg : reg * n_wg + wg) * cap + c) * CB;
 			if (CB == 128) {
 				*reinterpret_cast<uint4*>(p + l4 * 16) = v[u];
 			} else if (CB == 96) {
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(1024) void chunk_kernel(const uint4* __restrict__ i
 	}
 }
 
-template <int CB>
+template <int CB, int LAYOUT = 0>
 static void run(const uint4* in, uint8_t* out, uint32_t cap, uint32_t rounds, uint32_t n_wg)
 {
 	hipEvent_t a, b;
@@ -73,7 +76,7 @@ static void run(const uint4* in, uint8_t* out, uint32_t cap, uint32_t rounds, ui
 	float best = 1e30f;
 	for (int it = 0; it < 4; ++it) {
 		CK(hipEventRecord(a, 0));
-		hipLaunchKernelGGL(chunk_kernel<CB>, dim3(n_wg), dim3(1024), 0, 0, in, out, cap, rounds, n_wg);
+		hipLaunchKernelGGL((chunk_kernel<CB, LAYOUT>), dim3(n_wg), dim3(1024), 0, 0, in, out, cap, rounds, n_wg);
 		CK(hipEventRecord(b, 0));
 		CK(hipEventSynchronize(b));
 		float ms;
@@ -82,8 +85,8 @@ static void run(const uint4* in, uint8_t* out, uint32_t cap, uint32_t rounds, ui
 			best = ms;
 	}
 	const double chunks = (double)n_wg * rounds * 512, rd = chunks * 128, wr = chunks * CB;
-	std::printf("chunk %3d B: %8.3f ms  read %.1f GB + written %.1f GB -> %.0f GB/s  (%.3f us per 1e6 chunks... %.2f ns/chunk-equiv)\n",
-	            CB, best, rd / 1e9, wr / 1e9, (rd + wr) / best / 1e6, best * 1e3 / (chunks / 1e6), best * 1e6 / chunks);
+	std::printf("layout %d chunk %3d B: %8.3f ms  read %.1f GB + written %.1f GB -> %.0f GB/s  (%.3f us per 1e6 chunks... %.2f ns/chunk-equiv)\n",
+	            LAYOUT, CB, best, rd / 1e9, wr / 1e9, (rd + wr) / best / 1e6, best * 1e3 / (chunks / 1e6), best * 1e6 / chunks);
 }
 
 int main(int argc, char** argv)
@@ -103,5 +106,8 @@ int main(int argc, char** argv)
 	run<96>(in, out, cap, rounds, n_wg);
 	run<80>(in, out, cap, rounds, n_wg);
 	run<128>(in, out, cap, rounds, n_wg);
+	run<128, 1>(in, out, cap, rounds, n_wg);
+	run<128, 0>(in, out, cap, rounds, n_wg);
+	run<128, 1>(in, out, cap, rounds, n_wg);
 	return 0;
 }
