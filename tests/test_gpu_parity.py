@@ -1160,3 +1160,47 @@ def test_partitioned_ragged_layout_start_bitmap(bf, shape):
     assert bool(torch.equal(res["direct"][0], res["partitioned"][0])), "hit bitmaps differ"
     want_clean = int(np.clip(np.diff(starts) - (k - 1), 0, None).sum())
     assert abs(res["direct"][2][0] - want_clean) <= 2 * k  # (the N and the foreign stretch's seams)
+
+
+@pytest.mark.parametrize("n_seeds,h2,k,L", [(6, 1, 31, 150), (8, 1, 25, 100), (4, 2, 47, 151), (2, 1, 96, 250), (3, 1, 8, 60)])
+def test_partitioned_spaced_seed_union_list_shapes(bf, oracle, n_seeds, h2, k, L):
+    """Random spaced seeds through pass A's union list of don't-care offsets (seq_core.hpp): more than four hashes per
+    k-mer (rounds and groups of two windows), h2 > 1 (the seeds' values picked with a select chain), every mask class of
+    odd size (the zero-row filler), offsets every seed leaves out, a seed without don't-cares, and -- k = 96 -- more than
+    64 distinct offsets, which pass A does not take (the direct kernels answer, also in "partitioned" mode).  Against
+    the direct kernels and, for a slice of the reads, against the oracle's stHashIterator walk (vendor/stHashIterator.hpp:53-104)."""
+    import torch
+
+    rng = np.random.RandomState(100 * n_seeds + h2 + k)
+    seeds = []
+    for j in range(n_seeds):
+        s = (rng.random_sample(k) < (0.35 if k >= 96 else 0.75)).astype(int)
+        s[k // 2] = 0            # left out by every seed: folded into the common base
+        if j == 1:
+            s[:] = 1             # a seed that cares about every position
+            s[k // 2] = 0
+        seeds.append("".join("1" if x else "0" for x in s))
+    bits, h = 1 << 29, n_seeds * h2
+    reads = bf.synth_reads_device(11, 0, 30000, L)
+    reads[700:705] = ord("N")
+    a, b = bf.BloomFilter(bits, h, k), bf.BloomFilter(bits, h, k)
+    for f, mode in ((a, "direct"), (b, "partitioned")):
+        f.setSpacedSeeds(seeds, h2)
+        f.setInsertMode(mode)
+        f.setQueryMode(mode)
+        f.insertSeqs(reads, read_len=L)
+    torch.cuda.synchronize()
+    assert a.getPop() == b.getPop() > 0
+    assert (a.download() == b.download()).all()
+    q = torch.cat([reads[: 4000 * L], bf.synth_reads_device(12, 0, 30, L)])
+    ha, _, ca = a.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    hb, _, cb = b.containsSeqs(q, read_len=L, want_valid=False, want_counts=True)
+    torch.cuda.synchronize()
+    assert ca.tolist() == cb.tolist() and bool((ha == hb).all().item())
+    # the bits the oracle's iterator sets for the first reads are all set
+    body = b.download()
+    host = bytes(reads[: 20 * L].cpu().numpy())
+    for r in range(20):
+        pos, hv, _ = oracle.sthash_seq(host[r * L: (r + 1) * L], seeds, h2, k)
+        p = (hv % np.uint64(bits)).ravel().astype(np.int64)
+        assert ((body[p >> 3] >> (p & 7)) & 1).all(), "read %d" % r
