@@ -11,6 +11,25 @@
 
 namespace btlbf {
 
+// A kernel argument read again from the kernarg segment where it is used, instead of being held in scalar registers
+// for the whole kernel.  Pass A's tile loop lives at the limit of both register files; what the compiler cannot hold
+// it spills -- uniform values via two lane-spill registers and, beyond those, to SCRATCH --, and a scratch reload
+// inside the loop waits for every vector-memory operation in flight, the flush stores included.  Arguments that a tile
+// needs two or three times (the buffer, its length, the bitmaps) cost a scalar load each time instead: the pointer is
+// laundered through an empty asm, so the load cannot be hoisted out of the loop.
+template <class T>
+__device__ __forceinline__ T kernarg_reload(uint32_t byte_off)
+{
+	typedef const uint8_t __attribute__((address_space(4))) kbyte;
+	kbyte* kp = (kbyte*)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(kp));
+	return *(const T __attribute__((address_space(4)))*)(kp + byte_off);
+}
+// (SeqArgs is the first argument of both pass-A kernels: its fields lie at their offsets in the segment)
+#define KARG(field) kernarg_reload<decltype(SeqArgs::field)>((uint32_t)offsetof(SeqArgs, field))
+#define KARG_LAYOUT(field) \
+	kernarg_reload<decltype(LayoutParams::field)>((uint32_t)(offsetof(SeqArgs, layout) + offsetof(LayoutParams, field)))
+
 // ---- pass A --------------------------------------------------------------------------------------
 // bin = position >> bin_shift ; entry = position & ((1 << bin_shift) - 1); region = blockIdx.x
 // (gridDim.x == out.regions).  `position` is local to a.mod's shard window (the whole filter in
@@ -301,7 +320,6 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	const uint32_t bin_mask = (uint32_t)(a.mod.mask >> bin_shift);
 	const uint32_t ent_mask_p2 = ent_mask & (uint32_t)a.mod.mask; // a filter smaller than one bin
 	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, ((uint64_t)b << bin_shift) | v); };
-	const uint64_t out_bytes = ((a.len + 63) / 64) * 8;
 	uint32_t my_valid = 0;
 
 	const uint64_t t_begin = a.first_tile + (uint64_t)blockIdx.x * a.tiles_per_block;
@@ -333,14 +351,14 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	// staging is the Y waves' job: 6 words per thread, requested at the start of the tile's second round (the Y
 	// waves have no hashing to do there) and converted behind that round's first barrier
 	StageRaw<kStageKW> raw;
-	auto stage_request = [&](uint64_t t) { seq_stage_load<NY, kStageKW>(raw, a.seq, a.len, k, t * (uint64_t)tile_bytes, span, ytid); };
+	auto stage_request = [&](uint64_t t) { seq_stage_load<NY, kStageKW>(raw, KARG(seq), KARG(len), k, t * (uint64_t)tile_bytes, span, ytid); };
 	auto stage_convert = [&](uint64_t t) {
 		const uint64_t g0 = t * (uint64_t)tile_bytes;
 		if (grid)
-			seq_stage_convert_grid<NY, kStageKW>(raw, tile, sh, a.seq, a.len, L, a.rg_lpad, tile_bytes, g0, ytid,
+			seq_stage_convert_grid<NY, kStageKW>(raw, tile, sh, KARG(seq), KARG(len), L, a.rg_lpad, tile_bytes, g0, ytid,
 			                                     masked ? rmask : nullptr, (uint32_t)(t * a.rg_reads) & 31u);
 		else
-			seq_stage_convert<NY, kStageKW, false, false, true>(raw, tile, tile_cap, sh, a.seq, a.len, a.layout, k, g0, tile_off,
+			seq_stage_convert<NY, kStageKW, false, false, true>(raw, tile, tile_cap, sh, KARG(seq), KARG(len), a.layout, k, g0, tile_off,
 			                                                    span, ytid, sb && t != t_begin ? sbm : nullptr);
 		tile_off = seq_next_tile_off(tile_off, tile_step, L);
 	};
@@ -354,16 +372,19 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	// the first candidate of every staging thread is requested together with the tile's words (before phase 1's stores)
 	auto starts_request = [&](uint64_t& p_mine, uint64_t& p_last) {
 		const uint64_t s = s_base + (uint32_t)ytid, sl = s_base + (uint32_t)(NY - 1);
-		p_mine = s <= a.layout.n_seqs ? a.layout.starts[s] : ~0ull;
-		p_last = sl <= a.layout.n_seqs ? a.layout.starts[sl] : ~0ull; // (one address per wave)
+		const uint64_t* const starts = KARG_LAYOUT(starts);
+		const uint64_t n_seqs = KARG_LAYOUT(n_seqs);
+		p_mine = s <= n_seqs ? starts[s] : ~0ull;
+		p_last = sl <= n_seqs ? starts[sl] : ~0ull; // (one address per wave)
 	};
 	auto mark_ahead = [&](uint64_t T, uint64_t p, const uint64_t p_last) {
 		const uint64_t g0 = T * (uint64_t)tile_bytes;
-		uint64_t need = a.len > g0 ? a.len - g0 : 0;
+		const uint64_t len = KARG(len);
+		uint64_t need = len > g0 ? len - g0 : 0;
 		if (need > span)
 			need = span;
 		const uint64_t end = g0 + need, nxt = g0 + tile_bytes;
-		const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(a.seq + g0) & 3);
+		const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(KARG(seq) + g0) & 3);
 		uint32_t cnt = 0;
 		uint64_t s = s_base + (uint32_t)ytid, sl = s_base + (uint32_t)(NY - 1), pl = p_last;
 		for (;;) {
@@ -379,8 +400,8 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 				break;
 			s += NY;
 			sl += NY;
-			p = s <= a.layout.n_seqs ? a.layout.starts[s] : ~0ull;
-			pl = sl <= a.layout.n_seqs ? a.layout.starts[sl] : ~0ull;
+			p = s <= KARG_LAYOUT(n_seqs) ? KARG_LAYOUT(starts)[s] : ~0ull;
+			pl = sl <= KARG_LAYOUT(n_seqs) ? KARG_LAYOUT(starts)[sl] : ~0ull;
 		}
 		if ((ytid & 63) == 0 && cnt)
 			atomicAdd(&sb_cnt, cnt);
@@ -536,7 +557,7 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 #endif
 	for (; t < t_end; ++t) {
 		const uint64_t g0 = t * (uint64_t)tile_bytes;
-		li0 = grid ? grid_li0 : tid * kPartW + (uint32_t)(reinterpret_cast<uintptr_t>(a.seq + g0) & 3);
+		li0 = grid ? grid_li0 : tid * kPartW + (uint32_t)(reinterpret_cast<uintptr_t>(KARG(seq) + g0) & 3);
 		vmask = 0;
 		if (sb && isY) {
 			// the start bitmap was read by the conversion of this tile (two barriers ago) and is marked again in this
@@ -564,7 +585,7 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 				// and the X waves would find the Y waves still there when they arrive at the barrier
 				stage_request(t + 1);
 				if ((uint32_t)ytid < n_mw)
-					mask_word = a.read_mask[(((t + 1) * a.rg_reads) >> 5) + (uint32_t)ytid];
+					mask_word = KARG(read_mask)[(((t + 1) * a.rg_reads) >> 5) + (uint32_t)ytid];
 				if (sb) {
 					if (t == t_begin) { // (uniform: kept in scalar registers)
 						const uint64_t v = sh.start_lo;
@@ -614,14 +635,17 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			const uint8_t* bm8 = reinterpret_cast<const uint8_t*>(bm);
 			const uint64_t ob0 = g0 >> 3; // tiles are whole bytes of the bitmaps
 			// the buffer's last tile also writes the (zero) bytes up to the end of the bitmaps' last 64-bit word
+			const uint64_t len = KARG(len), out_bytes = ((len + 63) / 64) * 8;
 			const uint64_t left = out_bytes > ob0 ? out_bytes - ob0 : 0;
-			const uint32_t n_out = g0 + tile_bytes >= a.len || left < tile_bytes / 8 ? (uint32_t)left : tile_bytes / 8;
+			const uint32_t n_out = g0 + tile_bytes >= len || left < tile_bytes / 8 ? (uint32_t)left : tile_bytes / 8;
+			uint8_t* const vb = KARG(valid_bits);
+			uint8_t* const hb = KARG(hit_bits);
 			for (uint32_t i = ltid; i < n_out; i += NT) {
 				const uint8_t v = i < tile_bytes / 8 ? bm8[i] : (uint8_t)0;
-				if (a.valid_bits)
-					a.valid_bits[ob0 + i] = v;
-				if (a.hit_bits)
-					a.hit_bits[ob0 + i] = v; // a query starts from "every clean window hits"
+				if (vb)
+					vb[ob0 + i] = v;
+				if (hb)
+					hb[ob0 + i] = v; // a query starts from "every clean window hits"
 			}
 			for (uint32_t i = ltid; i < grid_bm_words; i += NT)
 				other[i] = 0;
@@ -629,11 +653,13 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			// one byte of the per-window bitmaps per lane
 			static_assert(kPartW == 8, "one bitmap byte per lane");
 			const uint64_t ob = (g0 >> 3) + ltid;
-			if (ob < out_bytes) {
-				if (a.valid_bits)
-					a.valid_bits[ob] = (uint8_t)vmask;
-				if (a.hit_bits)
-					a.hit_bits[ob] = (uint8_t)vmask; // a query starts from "every clean window hits"
+			if (ob < ((KARG(len) + 63) / 64) * 8) {
+				uint8_t* const vb = KARG(valid_bits);
+				uint8_t* const hb = KARG(hit_bits);
+				if (vb)
+					vb[ob] = (uint8_t)vmask;
+				if (hb)
+					hb[ob] = (uint8_t)vmask; // a query starts from "every clean window hits"
 			}
 		}
 		my_valid += __popc(vmask);
