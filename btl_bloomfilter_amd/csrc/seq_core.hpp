@@ -20,9 +20,6 @@
 #ifndef BTLBF_SPACED_CHK
 #define BTLBF_SPACED_CHK 2
 #endif
-#ifndef BTLBF_SPACED_U8
-#define BTLBF_SPACED_U8 1
-#endif
 
 namespace btlbf {
 
@@ -430,7 +427,9 @@ struct WinHash {
 	}
 };
 
-// unaligned LDS reads (gfx950's DS unit takes unaligned b32/b64 addresses)
+// LDS reads at any byte address (gfx950's DS unit takes unaligned b32/b64 addresses -- but REPLAYS them: a misaligned
+// access costs several aligned ones, round-4 finding; the hot paths keep these reads aligned and use them unaligned only
+// for callers' misaligned buffers)
 __device__ __forceinline__ uint32_t lds_u32(const uint8_t* p)
 {
 	uint32_t v;
@@ -593,25 +592,13 @@ __device__ __forceinline__ void seq_lane_range(const uint8_t* tile, const SeqSha
 #pragma unroll
 					for (int c = 0; c < CHK; ++c) {
 						const uint32_t off = e[c] & 0xffffu;
-						if (GRP == 4) {
-#if BTLBF_SPACED_U8
-							span[c] = (uint32_t)bp[g0 + off] | ((uint32_t)bp[g0 + off + 1] << 8) | ((uint32_t)bp[g0 + off + 2] << 16) |
-							          ((uint32_t)bp[g0 + off + 3] << 24);
-#else
-							span[c] = lds_u32(bp + g0 + off);
-#endif
-						} else {
-#if BTLBF_SPACED_U8
-							// two byte reads: ONE unaligned ds_read_u16 (half of these addresses are odd) made the whole
-							// kernel 45 % slower -- 136 instead of 92 ms per 6x10^9 k-mers; misaligned LDS accesses are
-							// replayed on this chip, they are not a free convenience
-							span[c] = (uint32_t)bp[g0 + off] | ((uint32_t)bp[g0 + off + 1] << 8);
-#else
-							uint16_t s2;
-							__builtin_memcpy(&s2, bp + g0 + off, 2); // (unaligned ds_read_u16)
-							span[c] = s2;
-#endif
-						}
+						// byte reads: ONE unaligned ds_read_u16 per offset (half of these addresses are odd) made the whole kernel
+						// 45 % slower -- 136 instead of 92 ms per 6x10^9 k-mers; misaligned LDS accesses are replayed on this
+						// chip, they are not a free convenience
+						span[c] = 0;
+#pragma unroll
+						for (int q = 0; q < GRP; ++q)
+							span[c] |= (uint32_t)bp[g0 + off + q] << (8 * q);
 					}
 				};
 				auto lookups = [&](const uint32_t (&e)[CHK], const uint32_t (&span)[CHK], U64x2 (&tt)[CHK][GRP]) {
