@@ -111,6 +111,7 @@ _PROTOS = {
     "btlbf_route_seqs": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(Layout), C.c_uint64, C.c_uint, C.c_uint, C.c_int, _P, _P,
                                    _P, _P, _P, _P, C.c_uint64, _P, _P]),
     "btlbf_route_geometry": (C.c_int, [_P, C.c_uint64, C.POINTER(Layout), C.c_uint, C.c_uint, C.POINTER(C.c_uint32)]),
+    "btlbf_owner_scratch_bytes": (C.c_int, [_P, C.c_uint64, C.POINTER(Layout), C.c_uint, C.c_uint, C.POINTER(C.c_uint64)]),
     "btlbf_apply_routed_bins": (C.c_int, [_P, _P, _P, C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.POINTER(Layout),
                                           C.c_uint, C.c_int, _P, C.c_uint64, _P, _P]),
     "btlbf_apply_routed": (C.c_int, [_P, _P, _P, C.c_uint, C.c_uint64, C.POINTER(Layout), C.c_uint, C.c_int, _P,

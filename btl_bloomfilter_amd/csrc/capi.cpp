@@ -2519,6 +2519,24 @@ extern "C" int btlbf_route_geometry(btlbf_filter* f, uint64_t plan_len, const bt
 	return BTLBF_OK;
 }
 
+extern "C" int btlbf_owner_scratch_bytes(btlbf_filter* f, uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards,
+                                         unsigned n_blocks, uint64_t* bytes)
+{
+	FilterLock lk__(f);
+	if (!f || !bytes)
+		return fail(BTLBF_EINVAL, "null argument");
+	const LayoutParams lay = layout_params(layout);
+	RoutePlan rp;
+	int rc = route_plan(f, plan_len, lay, n_shards, rp);
+	if (rc)
+		return rc;
+	PartPlan pl;
+	if ((rc = owner_plan(f, rp, lay, plan_len, n_blocks ? n_blocks : n_shards, n_shards, pl)))
+		return rc;
+	*bytes = pl.bytes_total;
+	return BTLBF_OK;
+}
+
 extern "C" int btlbf_apply_routed_bins(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
                                        unsigned first_bin, unsigned n_bins, uint64_t plan_len,
                                        const btlbf_layout* layout, unsigned n_shards, int query, uint64_t* fail_list,

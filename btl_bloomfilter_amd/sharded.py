@@ -171,6 +171,13 @@ class HipShardOps:
         _lib.check(self.L.btlbf_route_geometry(self.f, plan_len, C.byref(lay), self.world, self.world, out))
         return tuple(int(v) for v in out)
 
+    def owner_scratch_bytes(self, plan_len, read_len):
+        """bytes of scratch apply_routed[_bins] allocates inside the filter for batches of plan_len bytes of reads"""
+        out = C.c_uint64()
+        lay = self._lay(read_len)
+        _lib.check(self.L.btlbf_owner_scratch_bytes(self.f, plan_len, C.byref(lay), self.world, self.world, C.byref(out)))
+        return out.value
+
     def apply_routed_bins(self, recv_ent, recv_cnt, n_blocks, first_bin, n_bins, plan_len, read_len, query, fail_list,
                           fail_count):
         lay = self._lay(read_len)
@@ -438,7 +445,7 @@ class ShardedBloomFilter:
         dist.all_gather(outs, pad, group=self.group)
         return torch.cat([o[:c] for o, c in zip(outs, cnts)]).to(dev)
 
-    def _route_batch_bytes(self, reads, read_len, n_slots=1, recv_sets=0.0):
+    def _route_batch_bytes(self, reads, read_len, n_slots=1, recv_sets=0.0, exact=None):
         """bytes of read buffer per batch (same on every rank): n_slots send block sets, the receive
         buffers (recv_sets block sets: two groups of a block set) and two split levels must fit in free HBM"""
         longest = self._max_over_ranks(reads.numel())
@@ -452,6 +459,27 @@ class ShardedBloomFilter:
         else:
             free = 1 << 40
         free = -self._max_over_ranks(-free)  # the smallest over ranks: every rank must plan the same batch
+        unit = 64 * read_len
+        if exact is not None and hasattr(self.ops, "owner_scratch_bytes") and not self.batch_bytes_cap:
+            # the buffers of a pass added up exactly (send block sets, receive groups, the owner's scratch inside the
+            # filter, spill and fail lists), for the fewest batches that leave a tenth of the free HBM untouched: the
+            # rule of thumb below keeps a fifth and more, which at BASELINE config 4 (128 GiB shards) is the difference
+            # between five batches per pass and four -- one sweep of the shard per pass
+            n_slots_e, spw, W, r_slots, G, exchanging = exact
+            lists = n_slots_e * self.SPILL_CAP * 8 + self.FAIL_CAP * 8 + (64 << 20)
+            # (the owner's scratch of an earlier pass is still allocated inside the filter -- it only grows -- and will
+            # be used again: it is not free, but it is not an additional need either)
+            held = getattr(self, "_owner_scratch", 0)
+            for n_b in range(1, 4097):
+                batch = -(-(-(-longest // n_b)) // unit) * unit
+                ent_b, cnt_b = self.ops.route_plan(batch, read_len)
+                owner = self.ops.owner_scratch_bytes(batch, read_len)
+                total = n_slots_e * spw * (ent_b + cnt_b) + lists + max(owner - held, 0)
+                if exchanging:
+                    total += r_slots * W * (ent_b // G + cnt_b // G)
+                if total <= 0.90 * free or batch <= unit:
+                    self._owner_scratch = max(held, owner)
+                    return batch, -(-longest // batch)
         # per read byte: h*(L-k+1)/L probes * 4 B per entry, ~1.1x capacity; block sets: send, receive
         # (when there are peers) + the owner's split levels, which hold 1/8 of a batch
         sets = n_slots + recv_sets + 0.4
@@ -491,7 +519,8 @@ class ShardedBloomFilter:
         G = bins // gb if exchanging else 1
         r_slots = 2 if G > 1 else 1
         batch, n_batches = self._route_batch_bytes(reads, read_len, n_slots / n_win,
-                                                   r_slots / G if exchanging else 0.0)
+                                                   r_slots / G if exchanging else 0.0,
+                                                   exact=(n_slots, spw, W, r_slots, G, exchanging))
         if n_batches == 0:
             return True
         n_jobs = n_batches * n_win

@@ -369,6 +369,12 @@ int btlbf_apply_routed(btlbf_filter* f, const void* recv_ent, const void* recv_c
                        uint64_t* fail_list, uint64_t fail_cap, uint64_t* fail_count, void* stream);
 int btlbf_route_geometry(btlbf_filter* f, uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards,
                          unsigned n_blocks, uint32_t* out4);
+/* Bytes of partition scratch the OWNER side (btlbf_apply_routed / btlbf_apply_routed_bins) allocates inside the filter
+ * for batches planned with `plan_len`, `n_blocks` origin blocks (0: n_shards): lets the caller size its batches from
+ * the free HBM exactly instead of by rule of thumb (sharded.py plans BASELINE config 4 -- 1 TiB on 8 GPUs, SURVEY 8e --
+ * with four batches per pass instead of five that way).  No device work. */
+int btlbf_owner_scratch_bytes(btlbf_filter* f, uint64_t plan_len, const btlbf_layout* layout, unsigned n_shards,
+                              unsigned n_blocks, uint64_t* bytes);
 int btlbf_apply_routed_bins(btlbf_filter* f, const void* recv_ent, const void* recv_cnt, unsigned n_blocks,
                             unsigned first_bin, unsigned n_bins, uint64_t plan_len, const btlbf_layout* layout,
                             unsigned n_shards, int query, uint64_t* fail_list, uint64_t fail_cap,
