@@ -102,9 +102,27 @@ __device__ __forceinline__ void seq_setup_tables(SeqShared& sh, const HashParams
 		// fwd[c] = init_tab[c][0], rev[c] = out_tab[c][1] (internal.hpp)
 		const uint32_t k = hp.k;
 		U64x2* pt = reinterpret_cast<U64x2*>(spaced_lds);
-		for (uint32_t i = tid; i < (k + 1) * kNumCodes; i += NT) {
-			const uint32_t pos = i / kNumCodes, c = i % kNumCodes;
-			pt[i] = pos < k ? U64x2{srol_n(hp.init_tab[c][0], k - 1 - pos), srol_n(hp.out_tab[c][1], pos)} : U64x2{0, 0};
+		auto term = [&](uint32_t pos, uint32_t c) {
+			return U64x2{srol_n(hp.init_tab[c][0], k - 1 - pos), srol_n(hp.out_tab[c][1], pos)};
+		};
+		if (SPACED) {
+			for (uint32_t i = tid; i < (k + 1) * kNumCodes; i += NT) {
+				const uint32_t pos = i / kNumCodes, c = i % kNumCodes;
+				pt[i] = pos < k ? term(pos, c) : U64x2{0, 0};
+			}
+		} else {
+			// plain ntHash: the table is indexed by PAIRS of bases -- row j (256 bytes) holds, for the 16 pairs of A C G T,
+			// the sum of the terms of positions 2j and 2j+1; an odd k ends with one single-base row of all 8 codes.  Same
+			// bytes as the single-base table, half the lookups and XORs in a lane's start-up (seq_lane_range); windows
+			// with one of the raw-byte codes 4..7 take the Horner form there
+			const uint32_t pairs = k / 2;
+			for (uint32_t i = tid; i < pairs * 16; i += NT) {
+				const uint32_t j = i / 16, c1 = (i / 4) % 4, c2 = i % 4;
+				const U64x2 a = term(2 * j, c1), b = term(2 * j + 1, c2);
+				pt[i] = U64x2{a.x ^ b.x, a.y ^ b.y};
+			}
+			if ((k & 1) && tid < kNumCodes)
+				pt[pairs * 16 + tid] = term(k - 1, tid);
 		}
 	}
 	if (SPACED) {
@@ -475,9 +493,49 @@ __device__ __forceinline__ void seq_lane_range(const uint8_t* tile, const SeqSha
 		uint64_t fh = 0, rh = 0;
 		uint32_t good = 0; // "good" bases among the window's k bases (the first base's flag is taken out below)
 		uint32_t i = 0;
-		if (hp.use_pos_tab) {
-			// first window from the positional table: four bases per LDS word, one 16-byte entry and two
-			// 64-bit XORs per base
+		if (hp.use_pos_tab && !SPACED) {
+			// first window from the PAIR table (seq_setup_tables): four bases per LDS word, one 16-byte entry and two
+			// 64-bit XORs per two bases.  The entry of bases (c1, c2) of pair j sits at j * 256 + c1 * 64 + c2 * 16; a
+			// staged byte holds its code in bits 6:4, so c1 * 64 + c2 * 16 = (b1 << 2 & 0xc0) | (b2 & 0x30) for the codes
+			// 0..3 -- bit 6 of a byte marks the raw-byte codes 4..7, which this table does not hold
+			uint32_t raw = 0;
+			for (; i + 4 <= k; i += 4) {
+				const uint32_t w = lds_u32(bp + i);
+				good += __popc(w & (kBaseGood * 0x01010101u));
+				raw |= w;
+				const uint32_t x = w & 0x30303030u;
+				const U64x2 t0 = tab16(pos_tab, i * 128 + (((x << 2) | (x >> 8)) & 0xf0u));
+				const U64x2 t1 = tab16(pos_tab, i * 128 + 256 + (((x >> 14) | (x >> 24)) & 0xf0u));
+				fh ^= t0.x ^ t1.x;
+				rh ^= t0.y ^ t1.y;
+			}
+			if (i + 2 <= k) {
+				const uint32_t e0 = bp[i], e1 = bp[i + 1];
+				good += ((e0 / kBaseGood) & 1) + ((e1 / kBaseGood) & 1);
+				raw |= e0 | e1;
+				const U64x2 tt = tab16(pos_tab, i * 128 + ((e0 & 0x30u) << 2) + (e1 & 0x30u));
+				fh ^= tt.x;
+				rh ^= tt.y;
+				i += 2;
+			}
+			if (i < k) { // odd k: the last base through the single-base row behind the pairs
+				const uint32_t e = bp[i];
+				good += (e / kBaseGood) & 1;
+				const U64x2 tt = tab16(pos_tab, i * 128 + (e & kCodeOff));
+				fh ^= tt.x;
+				rh ^= tt.y;
+				++i;
+			}
+			if (raw & 0x40404040u) { // one of the bytes 1 3 4 5 7 among the k bases: the Horner form (rare)
+				fh = rh = 0;
+				for (uint32_t q = 0; q < k; ++q) {
+					const U64x2 tt = tab16(sh.init_tab, bp[q] & kCodeOff);
+					fh = srol1(fh) ^ tt.x;
+					rh = sror1(rh) ^ tt.y;
+				}
+			}
+		} else if (hp.use_pos_tab) {
+			// (spaced seeds keep the single-base table: their don't-care terms are looked up in it)
 			for (; i + 4 <= k; i += 4) {
 				const uint32_t w = lds_u32(bp + i);
 				good += __popc(w & (kBaseGood * 0x01010101u));
