@@ -530,6 +530,8 @@ void fill_mod(ModParams& m, uint64_t size, uint64_t lo, uint64_t len)
 	m.mask = size - 1;
 	// floor(2^64 / size) for size >= 2 that is not a power of two == floor((2^64-1)/size)
 	m.magic = m.pow2 ? 0 : (~0ULL) / size;
+	m.magic32 = (m.magic >> 32) || (size >> 63) ? 0 : (uint32_t)m.magic;
+	m.neg_size = 0 - size;
 	m.shard_lo = lo;
 	m.shard_len = len;
 	m.shard_shift = 0xffffffffu;
@@ -1468,6 +1470,7 @@ struct PartLevel {
 	uint32_t regions = 0; // writers per bin
 	uint32_t cap = 0;     // chunks per region
 	uint32_t shift = 0;   // log2(positions per bin)
+	uint32_t wseg = 0;    // level 0 only: bins of `wseg` segments each instead (plan_level0); `shift` is then unused
 	uint32_t alloc_bins = 0; // bins the arrays hold at a time (== bins unless the level is processed in groups)
 	uint64_t cnt_bytes = 0, ent_bytes = 0;
 	uint32_t* cnt = nullptr;
@@ -1555,23 +1558,32 @@ uint32_t split_slices(uint32_t bins_g, uint32_t r_in, uint32_t cus)
 // append the split levels that take bins of 2^lv[0].shift positions down to segments
 bool plan_splits(PartPlan& pl, uint32_t regions_in_total, uint32_t cus = 256)
 {
-	const uint32_t rb = pl.lv[0].shift - pl.seg_shift;
 	pl.n_levels = 1;
-	if (rb == 0)
-		return true;
-	if (rb > 20)
-		return false;
-	const uint32_t fan[2] = {rb <= 10 ? rb : rb - rb / 2, rb <= 10 ? 0 : rb / 2};
 	uint32_t regions_in = regions_in_total;
-	for (int j = 0; j < 2 && fan[j]; ++j) {
-		PartLevel& in = pl.lv[pl.n_levels - 1];
-		PartLevel& o = pl.lv[pl.n_levels];
-		o.P = 1u << fan[j];
-		o.bins = in.bins * o.P;
-		o.shift = in.shift - fan[j];
-		o.regions = split_slices(in.bins, regions_in, cus);
-		regions_in = o.regions;
-		++pl.n_levels;
+	if (pl.lv[0].wseg) { // bins of wseg segments: one split pass, wseg ways, straight to (real) segment numbers
+		PartLevel& o = pl.lv[1];
+		o.P = pl.lv[0].wseg;
+		o.bins = pl.lv[0].bins * o.P;
+		o.shift = pl.seg_shift;
+		o.regions = split_slices(pl.lv[0].bins, regions_in, cus);
+		pl.n_levels = 2;
+	} else {
+		const uint32_t rb = pl.lv[0].shift - pl.seg_shift;
+		if (rb == 0)
+			return true;
+		if (rb > 20)
+			return false;
+		const uint32_t fan[2] = {rb <= 10 ? rb : rb - rb / 2, rb <= 10 ? 0 : rb / 2};
+		for (int j = 0; j < 2 && fan[j]; ++j) {
+			PartLevel& in = pl.lv[pl.n_levels - 1];
+			PartLevel& o = pl.lv[pl.n_levels];
+			o.P = 1u << fan[j];
+			o.bins = in.bins * o.P;
+			o.shift = in.shift - fan[j];
+			o.regions = split_slices(in.bins, regions_in, cus);
+			regions_in = o.regions;
+			++pl.n_levels;
+		}
 	}
 	// the split levels and the apply pass run in groups of level-0 bins (split a group all the way
 	// down, apply its segments, next group): the arrays of the split levels then hold one group
@@ -1676,6 +1688,15 @@ double probes_per_tile(const btlbf_filter* f, const PartTiling& tl)
 	return tl.windows_per_tile * f->hp.h + 1.0;
 }
 
+// how level-0 bins map to positions, for the kernels (PartSide::bin_wseg)
+void side_bins(PartSide& sd, const PartPlan& pl)
+{
+	sd.bin_wseg = pl.lv[0].wseg;
+	sd.bin_magic = pl.lv[0].wseg ? (uint32_t)(((1ull << 32) + pl.lv[0].wseg - 1) / pl.lv[0].wseg) : 0;
+	sd.bin_seg_shift = pl.seg_shift;
+	sd.bin_width = pl.lv[0].wseg << pl.seg_shift;
+}
+
 // run the split levels lv[1..] over the level-0 data `in0`, then the apply / test pass
 // in0 holds level-0 bins [bin_offset, bin_offset + n_bins0) of the local array (bin i of in0 = absolute bin
 // bin_offset + i); the whole array by default
@@ -1765,6 +1786,17 @@ bool plan_level0(const btlbf_filter* f, PartPlan& pl)
 		l0.bins = (uint32_t)((pl.n_seg + (1ull << b1) - 1) >> b1);
 		if (l0.shift > 32)
 			return false; // (cannot happen below 2^22 segments)
+		// A bin count that is no power of two leaves staging rings of pass A unused while the others take more
+		// entries per round than they are sized for: 3 x 2^37 bits gave 384 bins on the 512-ring geometry, a third
+		// more entries per ring and round, and pass A took 22.2 ms per 2.4x10^9 k-mers where a filter of 512 bins and the
+		// same reduction takes 18.6.  So the bins are made of a whole number of SEGMENTS instead, as many as fill the
+		// geometry's rings (768 segments per bin there, 512 bins); pass B then splits wseg ways.  One split level only.
+		const uint32_t rings = 1u << ceil_log2(l0.bins);
+		static const bool pow2_bins = getenv("BTLBF_POW2_BINS") != nullptr; // diagnostic: the old rule
+		if (l0.bins < rings && b1 <= 10 && !pow2_bins) {
+			l0.wseg = (uint32_t)((pl.n_seg + rings - 1) / rings);
+			l0.bins = (uint32_t)((pl.n_seg + l0.wseg - 1) / l0.wseg);
+		}
 	}
 	l0.P = l0.bins;
 	l0.alloc_bins = l0.bins;
@@ -1847,6 +1879,7 @@ int partitioned_insert(btlbf_filter* f, const SeqArgs& base, hipStream_t s, bool
 			sd.counting = f->kind == BTLBF_COUNTING8;
 			sd.late_buf = pl.late_buf;
 			sd.late_cap = pl.late_cap;
+			side_bins(sd, pl);
 			if (fresh) {
 				HIP_TRY(order_after_clear(f, s)); // this batch IS the clear: after the point it was asked for
 				sd.fresh = 1;
@@ -1942,6 +1975,7 @@ int partitioned_contains(btlbf_filter* f, const SeqArgs& base, uint8_t* hit_bits
 	sd.threshold = f->thr;
 	sd.late_buf = pl.late_buf;
 	sd.late_cap = pl.late_cap;
+	side_bins(sd, pl);
 	sd.pos_base = f->mod.shard_lo; // the fail set is keyed by global position
 	const int direct_op = sd.counting ? OP_CBF_QUERY : f->shard_count != 1 ? OP_BF_CONTAINS_WIN : OP_BF_CONTAINS;
 	uint64_t* table = sd.fail_list + tail.fail_cap;

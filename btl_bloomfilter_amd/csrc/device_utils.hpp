@@ -53,13 +53,19 @@ __device__ __forceinline__ uint64_t extra_hash(uint64_t b, uint64_t kms, uint32_
 // below 2^32, and so a quotient below 2^32: mulhi(hash, magic) is then two 32-bit multiplies instead of four, and
 // q * size a 32 x 64-bit product (same q, same remainder).  A 400-Gbit filter of no power-of-two size ran pass A at
 // 75 ms per 6x10^9 k-mers with the generic form, against 42 for 2^38 / 2^39 bits.
-__device__ __forceinline__ bool mod_small_magic(const ModParams& m) { return (uint32_t)(m.magic >> 32) == 0; }
+__device__ __forceinline__ bool mod_small_magic(const ModParams& m) { return m.magic32 != 0; }
 __device__ __forceinline__ uint64_t reduce_mod_small(uint64_t hash, const ModParams& m)
 {
-	const uint32_t mg = (uint32_t)m.magic, lo = (uint32_t)hash, hi = (uint32_t)(hash >> 32);
+	// Nine instructions: mul_hi + mad (q), mad + mul_lo + add (hash - q * size as hash + q * (2^64 - size)), sub, subb,
+	// a 32-bit compare and two selects.  Written on `magic32` and `neg_size`: from `(uint32_t)m.magic` inside a branch on
+	// `m.magic >> 32 == 0` the optimiser concludes zext(trunc(magic)) == magic and multiplies by both halves of it (a
+	// run-time zero) -- sixteen instructions, five of them 64-bit multiply-adds
+	const uint32_t mg = m.magic32, lo = (uint32_t)hash, hi = (uint32_t)(hash >> 32);
 	const uint32_t q = (uint32_t)(((uint64_t)hi * mg + __umulhi(lo, mg)) >> 32);
-	const uint64_t r = hash - ((uint64_t)q * (uint32_t)m.size + ((uint64_t)(q * (uint32_t)(m.size >> 32)) << 32));
-	return r >= m.size ? r - m.size : r;
+	const uint64_t r0 = hash + (uint64_t)q * (uint32_t)m.neg_size;
+	const uint64_t r = (uint64_t)((uint32_t)(r0 >> 32) + q * (uint32_t)(m.neg_size >> 32)) << 32 | (uint32_t)r0;
+	const uint64_t r2 = r + m.neg_size; // r - size; r < 2 * size and size < 2^63 (fill_mod): negative iff r < size
+	return (int32_t)(r2 >> 32) < 0 ? r : r2;
 }
 __device__ __forceinline__ uint64_t reduce_mod_big(uint64_t hash, const ModParams& m)
 {

@@ -45,6 +45,10 @@ struct ModParams {
 	uint64_t shard_len; // number of positions held locally (== size unless a shard)
 	uint32_t pow2;
 	uint32_t shard_shift; // log2(shard_len) if shard_len is a power of two else 0xffffffff
+	// sizes above 2^32 of no power of two: magic below 2^32, kept apart from `magic` (and 2^64 - size apart from
+	// `size`) so that the optimiser cannot tie them together again -- see reduce_mod_small; 0 otherwise
+	uint32_t magic32;
+	uint64_t neg_size;
 };
 
 // Everything the hash stage needs.  Tables are tiny and copied to LDS by each workgroup.
@@ -208,6 +212,11 @@ struct PartSide {
 	uint32_t late_cap;              // pass A's overlapped schedule: words of one late image (>= part_late_cap()) ...
 	uint32_t* late_buf;             // ... of [workgroup][round parity][late_cap]: where entries that found their ring
 	                                // full wait for the flush (nullptr: plain schedule)
+	// Level-0 bins of bin_wseg SEGMENTS each instead of 2^bin_shift positions (partition_core.hpp part_bin_of): a local
+	// array whose segment count is no power of two still fills all 2^n staging rings of pass A evenly.  0 = bins of
+	// 2^bin_shift positions.  bin_magic = ceil(2^32 / bin_wseg), bin_seg_shift = log2(positions per segment),
+	// bin_width = bin_wseg << bin_seg_shift = positions per bin (at most 2^30).
+	uint32_t bin_wseg, bin_magic, bin_seg_shift, bin_width;
 };
 // a late image mirrors the staging rings of a pass-A workgroup (partition_core.hpp kStageEntries): slot j of bin b's
 // row takes the (j+1)-th entry that found the ring of b full this round

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 	// a power-of-two filter taken whole: bin and entry are bit fields of the hash itself (no 64-bit `& mask` first)
 	const uint32_t bin_mask = (uint32_t)(a.mod.mask >> bin_shift);
 	const uint32_t ent_mask_p2 = ent_mask & (uint32_t)a.mod.mask; // a filter smaller than one bin
-	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, ((uint64_t)b << bin_shift) | v); };
+	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, part_bin_base(sd, b, bin_shift) + v); };
 	const uint64_t out_bytes = ((a.len + 63) / 64) * 8;
 	uint32_t my_valid = 0;
 
@@ -165,22 +165,31 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 				live |= (uint32_t)ok << w4;
 			// (no power of two: the form of the reduction is picked once per window, not once per probe)
 			auto probes = [&](auto&& position) {
+				auto place = [&](auto&& bin_of) {
 #pragma unroll
-				for (int i = 0; i < H; ++i) {
-					if (POW2 && !WINDOW) {
-						const uint64_t hv = wh.at(i);
-						bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
-						val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
-						continue;
+					for (int i = 0; i < H; ++i) {
+						if (POW2 && !WINDOW) {
+							const uint64_t hv = wh.at(i);
+							bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
+							val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
+							continue;
+						}
+						uint64_t p = position(wh.at(i));
+						if (WINDOW) {
+							p -= a.mod.shard_lo;
+							live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
+						}
+						bin_of(p, bin[w4 * H + i], val[w4 * H + i]);
 					}
-					uint64_t p = position(wh.at(i));
-					if (WINDOW) {
-						p -= a.mod.shard_lo;
-						live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
-					}
-					bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
-					val[w4 * H + i] = (uint32_t)p & ent_mask;
-				}
+				};
+				// (bins of sd.bin_wseg segments where the local array's segment count is no power of two: part_bin_of)
+				if (!(POW2 && !WINDOW) && sd.bin_wseg)
+					place([&](uint64_t p, uint32_t& b, uint32_t& v) { part_bin_of(sd, p, b, v); });
+				else
+					place([&](uint64_t p, uint32_t& b, uint32_t& v) {
+						b = (uint32_t)(p >> bin_shift);
+						v = (uint32_t)p & ent_mask;
+					});
 			};
 			if (POW2)
 				probes([&](uint64_t hv) { return hv & a.mod.mask; });
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	// a power-of-two filter taken whole: bin and entry are bit fields of the hash itself (no 64-bit `& mask` first)
 	const uint32_t bin_mask = (uint32_t)(a.mod.mask >> bin_shift);
 	const uint32_t ent_mask_p2 = ent_mask & (uint32_t)a.mod.mask; // a filter smaller than one bin
-	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, ((uint64_t)b << bin_shift) | v); };
+	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, part_bin_base(sd, b, bin_shift) + v); };
 	uint32_t my_valid = 0;
 
 	const uint64_t t_begin = a.first_tile + (uint64_t)blockIdx.x * a.tiles_per_block;
@@ -476,22 +485,31 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 			live |= (uint32_t)ok << w4;
 		// (no power of two: the form of the reduction is picked once per window, not once per probe)
 		auto probes = [&](auto&& position) {
+			auto place = [&](auto&& bin_of) {
 #pragma unroll
-			for (int i = 0; i < H; ++i) {
-				if (POW2 && !WINDOW) {
-					const uint64_t hv = wh.at(i);
-					bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
-					val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
-					continue;
+				for (int i = 0; i < H; ++i) {
+					if (POW2 && !WINDOW) {
+						const uint64_t hv = wh.at(i);
+						bin[w4 * H + i] = (uint32_t)(hv >> bin_shift) & bin_mask;
+						val[w4 * H + i] = (uint32_t)hv & ent_mask_p2;
+						continue;
+					}
+					uint64_t p = position(wh.at(i));
+					if (WINDOW) {
+						p -= a.mod.shard_lo;
+						live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
+					}
+					bin_of(p, bin[w4 * H + i], val[w4 * H + i]);
 				}
-				uint64_t p = position(wh.at(i));
-				if (WINDOW) {
-					p -= a.mod.shard_lo;
-					live |= (uint32_t)(ok && p < a.mod.shard_len) << (w4 * H + i);
-				}
-				bin[w4 * H + i] = (uint32_t)(p >> bin_shift);
-				val[w4 * H + i] = (uint32_t)p & ent_mask;
-			}
+			};
+			// (bins of sd.bin_wseg segments where the local array's segment count is no power of two: part_bin_of)
+			if (!(POW2 && !WINDOW) && sd.bin_wseg)
+				place([&](uint64_t p, uint32_t& b, uint32_t& v) { part_bin_of(sd, p, b, v); });
+			else
+				place([&](uint64_t p, uint32_t& b, uint32_t& v) {
+					b = (uint32_t)(p >> bin_shift);
+					v = (uint32_t)p & ent_mask;
+				});
 		};
 		if (POW2)
 			probes([&](uint64_t hv) { return hv & a.mod.mask; });

@@ -661,6 +661,21 @@ __device__ __forceinline__ void part_report_fail(const PartSide& sd, uint64_t po
 	if (i < sd.fail_cap)
 		sd.fail_list[i] = pos;
 }
+// Level-0 bins of w = sd.bin_wseg segments (w >= 2, no power of two in general): bin = segment / w by a multiply with
+// ceil(2^32 / w) -- exact for segment indices below 2^22 (error term (w * magic - 2^32) * segment < 2^10 * 2^22) --,
+// entry = position - bin * width, which is below width <= 2^30, so its low 32 bits are all of it.  Four instructions
+// (funnel shift, mul_hi, mul_lo, sub) against three for bit fields.
+__device__ __forceinline__ void part_bin_of(const PartSide& sd, uint64_t p, uint32_t& bin, uint32_t& val)
+{
+	bin = __umulhi((uint32_t)(p >> sd.bin_seg_shift), sd.bin_magic);
+	val = (uint32_t)p - bin * sd.bin_width;
+}
+// first position of level-0 bin `bin` (bins of 2^shift positions unless sd.bin_wseg)
+__device__ __forceinline__ uint64_t part_bin_base(const PartSide& sd, uint32_t bin, uint32_t shift)
+{
+	return sd.bin_wseg ? (uint64_t)bin * sd.bin_width : (uint64_t)bin << shift;
+}
+
 // overflow of an insert / contains pass: spill list when routing, else straight to the filter
 template <bool QUERY>
 __device__ __forceinline__ void part_direct(uint32_t* words, const PartSide& sd, uint64_t lp)

@@ -58,9 +58,9 @@ __global__ __launch_bounds__(kPartThreads) void part_split_kernel(void* filter, 
 	part_init<kPartThreads>(pl, out.P);
 	uint32_t* words = static_cast<uint32_t*>(filter);
 	const uint32_t sub_mask = (1u << sub_shift) - 1;
-	const uint64_t bin_base = (uint64_t)(b + abs_off) << in_shift;
+	const uint64_t bin_base = part_bin_base(sd, b + abs_off, in_shift);
 	auto ovf = [&](uint32_t sub, uint32_t v) {
-		part_direct<QUERY>(words, sd, bin_base | ((uint64_t)sub << sub_shift) | v);
+		part_direct<QUERY>(words, sd, bin_base + (((uint64_t)sub << sub_shift) | v)); // (+: a bin of wseg segments is not aligned)
 	};
 	const uint32_t bin0 = (b - first_in) * out.P;
 	const uint32_t n_regions_in = in.blocks * in.regions_per_block;

@@ -107,6 +107,39 @@ def test_clear_is_ordered_on_the_callers_stream_and_eager_after_device_ptr(bf):
     assert f.getPop() == 0
 
 
+@pytest.mark.parametrize("bits,window", [(3 << 32, False), (5 << 33, False), (7 << 34, True), (3 << 37, False), ((1 << 36) + (1 << 32), False)])
+def test_sizes_of_an_odd_multiple_of_2p32_partitioned_equals_direct(bf, bits, window):
+    """hash % size (BloomFilter.hpp:190) for sizes m * 2^s, s >= 32 (3 * 2^37 bits and the like): segment counts of no
+    power of two, so pass A's bins are a whole number of segments (capi.cpp plan_level0) and positions come from the
+    32-bit-quotient form of the reduction -- same reads through the direct kernels and the pipeline, identical arrays
+    and answers; `window`: as one shard of two, so that the WINDOW form of pass A runs too."""
+    import torch
+
+    require_hbm(2 * (bits // 8) + (8 << 30), "two filters of %d bits" % bits)
+    h, k, L, n = 4, 31, 150, 1_500_000
+    reads = bf.synth_reads_device(bits % 1009, 0, n, L)
+    if window:
+        a, b = bf.BloomFilter.shard(bits, 1, 2, h, k), bf.BloomFilter.shard(bits, 1, 2, h, k)
+    else:
+        a, b = bf.BloomFilter(bits, h, k), bf.BloomFilter(bits, h, k)
+    a.setInsertMode("direct")
+    b.setInsertMode("partitioned", scratch_bytes=3 << 30)
+    a.insertSeqs(reads, read_len=L)
+    b.insertSeqs(reads, read_len=L)
+    assert a.digest() == b.digest() and a.getPop() == b.getPop() > 0
+    if not window:
+        want = bits * -np.expm1(-n * (L - k + 1) * h / bits)  # uniform positions: what a wrong modulus would not give
+        assert abs(a.getPop() - want) < 1e-3 * want
+    q = torch.cat([reads[: 100_000 * L], bf.synth_reads_device(77, 0, 100_000, L)])
+    a.setQueryMode("direct")
+    b.setQueryMode("partitioned")
+    ha, va, ca = a.containsSeqs(q, read_len=L, want_counts=True)
+    hb, vb, cb = b.containsSeqs(q, read_len=L, want_counts=True)
+    assert torch.equal(ha, hb) and torch.equal(va, vb) and ca.tolist() == cb.tolist()
+    if not window:
+        assert ca.tolist()[1] >= 100_000 * 120
+
+
 def test_reference_adhoc_size_48857600000_bits_partitioned_equals_direct(bf):
     """Tests/AdHoc/ParallelFilter.cpp:141-145 sizes its filter at 48 857 600 000 bits: not a power of two, more than
     2^32 bytes.  The partitioned pipeline against the direct kernels, side by side (6.1 GB each)."""

@@ -538,12 +538,14 @@ def test_partitioned_equals_direct_odd_shapes(bf, oracle, bits, k, h):
         assert hashlib.sha256(a.download()).hexdigest() == hashlib.sha256(b.download()).hexdigest()
 
 
-def test_partitioned_small_scratch_many_batches_and_skew(bf):
+@pytest.mark.parametrize("bits", [1 << 30, 3 << 29, (5 << 28) + 192, 1_000_000_072])
+def test_partitioned_small_scratch_many_batches_and_skew(bf, bits):
     """a scratch cap forces several batches; 4000 copies of one read overflow their bins, which must
-    fall back to direct atomics instead of dropping entries"""
+    fall back to direct atomics instead of dropping entries.  Sizes of no power of two: level-0 bins are then a whole
+    number of segments (capi.cpp plan_level0), and the overflow paths of passes A and B rebuild positions from them"""
     import torch
 
-    bits, h, k, L = 1 << 30, 4, 31, 150
+    h, k, L = 4, 31, 150
     reads = bf.synth_reads_device(42, 0, 60000, L)
     skew = reads[:L].repeat(4000)
     buf = torch.cat([reads, skew, reads[: 1000 * L]])
@@ -555,6 +557,12 @@ def test_partitioned_small_scratch_many_batches_and_skew(bf):
     torch.cuda.synchronize()
     assert a.getPop() == b.getPop()
     assert hashlib.sha256(a.download()).hexdigest() == hashlib.sha256(b.download()).hexdigest()
+    b.setQueryMode("partitioned")  # (the scratch budget set above holds for queries too)
+    a.setQueryMode("direct")
+    q = torch.cat([skew[: 2000 * L], bf.synth_reads_device(5, 0, 3000, L), reads[: 3000 * L]])
+    ha, va, ca = a.containsSeqs(q, read_len=L, want_counts=True)
+    hb, vb, cb = b.containsSeqs(q, read_len=L, want_counts=True)
+    assert torch.equal(ha, hb) and torch.equal(va, vb) and ca.tolist() == cb.tolist()
 
 
 @pytest.mark.parametrize("n_seeds,h2", [(2, 2), (3, 1), (4, 2), (1, 5)])

@@ -32,5 +32,8 @@ sq)
 	QB_RAGGED=1 sq_pass passA_ragged 39 20000000 partitioned partitioned hitonly
 	QB_BITS='3*2**37' sq_pass passA_3x2p37 39 20000000 partitioned partitioned hitonly
 	;;
+sq3x) # one shape alone
+	QB_BITS='3*2**37' sq_pass passA_3x2p37 39 20000000 partitioned partitioned hitonly
+	;;
 esac
 echo session $1 done

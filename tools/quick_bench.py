@@ -23,6 +23,8 @@ def main():
     if os.environ.get("QB_SPACED"):  # BASELINE config 5: four spaced seeds x h2 = 1
         f.setSpacedSeeds(["1110111011101110111011101110111", "1101101101101101011011011011011",
                           "1111001111001111111001111001111", "1011101011101011101011101011101"], 1)
+    if os.environ.get("QB_PROFILE"):  # per-kernel HIP-event times of the last repetition
+        f.setProfiling(True)
     hit_only = len(sys.argv) > 5 and sys.argv[5] == "hitonly"  # skip the all-miss query (profiling runs)
     reads = m.synth_reads_device(42, 0, n_reads, L)
     q = reads if hit_only else m.synth_reads_device(43, 0, n_reads, L)
@@ -53,6 +55,10 @@ def main():
         print(json.dumps({"mode": mode, "log2_bits": lg, "reads": n_reads, "insert_Gkmers_s": kmers / ti / 1e9,
                           "query_hit_Gkmers_s": kmers / th / 1e9, "query_miss_Gkmers_s": kmers / tm / 1e9,
                           "hits": c1.tolist(), "miss": c2.tolist()}), flush=True)
+        if os.environ.get("QB_PROFILE"):
+            prof = f.getProfile(reset=True)
+            if rep == 2:
+                print(json.dumps({a: round(b[0] / b[1], 2) for a, b in prof.items() if b[1]}), flush=True)
 
 
 if __name__ == "__main__":
