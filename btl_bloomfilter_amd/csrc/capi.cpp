@@ -1592,6 +1592,11 @@ bool plan_splits(PartPlan& pl, uint32_t regions_in_total, uint32_t cus = 256)
 	pl.group_bins = 0;
 	if (pl.n_levels >= 2 && pl.lv[0].bins >= 16) {
 		pl.group_bins = (pl.lv[0].bins + 7) / 8;
+		if (const char* e = getenv("BTLBF_GROUP_BINS")) { // tuning knob: level-0 bins split + applied per launch pair
+			const int v = atoi(e);
+			if (v >= 1 && (uint32_t)v <= pl.lv[0].bins)
+				pl.group_bins = (uint32_t)v;
+		}
 		uint32_t bins_g = pl.group_bins, r_in = regions_in_total;
 		for (int j = 1; j < pl.n_levels; ++j) {
 			pl.lv[j].regions = split_slices(bins_g, r_in, cus);
@@ -1743,6 +1748,8 @@ int run_levels(btlbf_filter* f, PartPlan& pl, PartIn in0, const PartSide& sd, in
 // reads (all hits: four gathers per k-mer), the partitioned one 17.3 ms + 1.6 per 10^6 -- equal at 1.57 %.  (Round 2's
 // rule was 2 % for both: a batch of 2x10^6 reads was inserted in 48.7 ms instead of 30.4.)
 constexpr double kAutoInsertRatio = 0.0095, kAutoQueryRatio = 0.0165;
+// plan_level0: calls of this many probes or more (4x10^9 k-mers at h = 4) take 256 level-0 bins where 512 are the rule
+constexpr double kWideSplitProbes = 1.6e10;
 
 // decide between the direct (atomicOr per probe) and the partitioned insert
 // bit filters: insert; counting filters: incrementAll only (the conservative update of `insert` needs
@@ -1765,7 +1772,8 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 }
 
 // the segment size and the level-0 bins (pass A's output) of this filter's local array; false = no partitioned path
-bool plan_level0(const btlbf_filter* f, PartPlan& pl)
+// `call_probes`: probes of the whole call (0 = unknown), for the one choice that depends on the batch size
+bool plan_level0(const btlbf_filter* f, PartPlan& pl, double call_probes = 0)
 {
 	if (!plan_segments(f->mod.shard_len, pl, f->kind == BTLBF_COUNTING8 ? 0 : 3))
 		return false;
@@ -1775,6 +1783,13 @@ bool plan_level0(const btlbf_filter* f, PartPlan& pl)
 		l0.shift = pl.seg_shift;
 	} else { // split the segment index bits evenly between pass A and pass B
 		unsigned b1 = (ceil_log2(pl.n_seg) + 1) / 2; // pass B takes the larger half: pass A gains more from big rings
+		// 2^17 < segments <= 2^18 (bit filters of 8 .. 16 GiB): 512 bins and a 512-way split by that rule, or 256 bins
+		// and a 1024-way split.  Pass A is 6 % (plain ntHash: 40.2 -> 37.9 ms per 6x10^9 k-mers) to 8.5 % (four spaced
+		// seeds: 89.7 -> 82.1) faster on 128-entry rings; the 1024-way split pass costs the same per launch in batches
+		// of 6x10^9 k-mers and 0.4 ms more (of 1.8) in batches of 2.4x10^9 (tools/quick_bench.py with BTLBF_SPLIT_BITS,
+		// DESIGN.md B.2) -- so for large calls only.
+		if (ceil_log2(pl.n_seg) == 18 && call_probes >= kWideSplitProbes)
+			b1 = 10;
 		if (const char* e = getenv("BTLBF_SPLIT_BITS")) { // tuning knob: segment-index bits left to pass B
 			const int v = atoi(e);
 			if (v >= 1 && v <= 10 && ceil_log2(pl.n_seg) - v <= 10)
@@ -1809,7 +1824,7 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
                  uint8_t** extra, bool* ok, int mode, double auto_ratio)
 {
 	*ok = false;
-	if (!plan_level0(f, pl))
+	if (!plan_level0(f, pl, (double)base.len * f->hp.h * ((double)f->mod.shard_len / (double)f->mod.size)))
 		return BTLBF_OK;
 	PartLevel& l0 = pl.lv[0];
 	l0.regions = part_hash_regions(f->hp, l0.P, cu_count(f->device)); // pass-A workgroups: one or two per CU
@@ -2186,7 +2201,7 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 		PartGrid g;
 		// (up to a quarter of the reads cold: beyond that the lanes pass A spends on zero-staged reads cost more than
 		// gathering the warm reads costs -- at one read in two 76 instead of 43 ms of pass A per 10^8 reads)
-		if (4 * n_cold <= n_reads && plan_level0(f, pl0) && part_read_grid(f->hp, pl0.lv[0].P, a.layout, &g)) {
+		if (4 * n_cold <= n_reads && plan_level0(f, pl0, (double)a.len * f->hp.h) && part_read_grid(f->hp, pl0.lv[0].P, a.layout, &g)) {
 			const uint64_t szm[5] = {up(cold_len + 16), up(bitmap_bytes(cold_len) + 16), wv ? up(bitmap_bytes(cold_len) + 16) : 0,
 			                         up(n_cold * 4 + 16), a.hit_bits ? 0 : up(bitmap_bytes(a.len) + 16)};
 			uint64_t need = 0;
