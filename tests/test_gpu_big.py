@@ -140,19 +140,22 @@ def test_sizes_of_an_odd_multiple_of_2p32_partitioned_equals_direct(bf, bits, wi
         assert ca.tolist()[1] >= 100_000 * 120
 
 
-@pytest.mark.parametrize("spaced", [False, True])
-def test_2p37_bits_with_256_level0_bins_and_a_1024_way_split(bf, monkeypatch, spaced):
-    """calls of 4x10^9 k-mers and more plan a 2^37-bit filter (2^18 segments) as 256 bins x 1024 ways instead of 512 x
-    512 (capi.cpp plan_level0); the tests' batches are smaller than that, so the plan is forced here through the
-    tuning knob -- against the direct kernels, plain ntHash and config 5's spaced seeds"""
+@pytest.mark.parametrize("kind", ["plain", "spaced", "counting"])
+def test_2p18_segments_with_256_level0_bins_and_a_1024_way_split(bf, monkeypatch, kind):
+    """calls of 4x10^9 k-mers and more plan a filter of 2^18 segments (2^37 bits, 2^34 counters) as 256 bins x 1024 ways
+    instead of 512 x 512 (capi.cpp plan_level0); the tests' batches are smaller than that, so the plan is forced here
+    through the tuning knob -- against the direct kernels: plain ntHash, config 5's spaced seeds, incrementAll"""
     import torch
 
-    bits, h, k, L, n = 1 << 37, 4, 31, 150, 3_000_000
-    require_hbm(2 * (bits // 8) + (16 << 30), "two filters of 2^37 bits")
+    h, k, L, n = 4, 31, 150, 3_000_000
+    require_hbm(2 * (16 << 30) + (16 << 30), "two filters of 16 GiB")
     monkeypatch.setenv("BTLBF_SPLIT_BITS", "10")
     reads = bf.synth_reads_device(11, 0, n, L)
-    a, b = bf.BloomFilter(bits, h, k), bf.BloomFilter(bits, h, k)
-    if spaced:
+    if kind == "counting":
+        a, b = bf.CountingBloomFilter(1 << 34, h, k, 2), bf.CountingBloomFilter(1 << 34, h, k, 2)
+    else:
+        a, b = bf.BloomFilter(1 << 37, h, k), bf.BloomFilter(1 << 37, h, k)
+    if kind == "spaced":
         seeds = ["1110111011101110111011101110111", "1101101101101101011011011011011",
                  "1111001111001111111001111001111", "1011101011101011101011101011101"]
         a.setSpacedSeeds(seeds, 1)
@@ -160,11 +163,19 @@ def test_2p37_bits_with_256_level0_bins_and_a_1024_way_split(bf, monkeypatch, sp
     a.setInsertMode("direct")
     b.setInsertMode("partitioned", scratch_bytes=6 << 30)
     b.setProfiling(True)
-    a.insertSeqs(reads, read_len=L)
-    b.insertSeqs(reads, read_len=L)
+    for f in (a, b):
+        if kind == "counting":
+            f.insertSeqs(reads, read_len=L, increment_all=True)
+            f.insertSeqs(reads[: (n // 2) * L], read_len=L, increment_all=True)  # the first half twice: threshold 2
+        else:
+            f.insertSeqs(reads, read_len=L)
     prof = b.getProfile()
     assert prof["insert_hash"][1] >= 1 and prof["insert_split"][1] >= 8
-    assert a.digest() == b.digest() and a.getPop() == b.getPop() > 0
+    assert a.digest() == b.digest()
+    if kind == "counting":
+        assert a.popCount() == b.popCount() > 0 and a.filtered_popcount() == b.filtered_popcount() > 0
+    else:
+        assert a.getPop() == b.getPop() > 0
     q = torch.cat([reads[: 200_000 * L], bf.synth_reads_device(12, 0, 200_000, L)])
     a.setQueryMode("direct")
     b.setQueryMode("partitioned")
