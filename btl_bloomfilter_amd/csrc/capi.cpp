@@ -1772,6 +1772,12 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 }
 
 // the segment size and the level-0 bins (pass A's output) of this filter's local array; false = no partitioned path
+// probes a call over `len` bases sends to this filter's local array (a shard keeps its window's share)
+double call_probes(const btlbf_filter* f, uint64_t len)
+{
+	return (double)len * f->hp.h * ((double)f->mod.shard_len / (double)f->mod.size);
+}
+
 // `call_probes`: probes of the whole call (0 = unknown), for the one choice that depends on the batch size
 bool plan_level0(const btlbf_filter* f, PartPlan& pl, double call_probes = 0)
 {
@@ -1824,7 +1830,7 @@ int part_prepare(btlbf_filter* f, const SeqArgs& base, PartTail* tail, PartPlan&
                  uint8_t** extra, bool* ok, int mode, double auto_ratio)
 {
 	*ok = false;
-	if (!plan_level0(f, pl, (double)base.len * f->hp.h * ((double)f->mod.shard_len / (double)f->mod.size)))
+	if (!plan_level0(f, pl, call_probes(f, base.len)))
 		return BTLBF_OK;
 	PartLevel& l0 = pl.lv[0];
 	l0.regions = part_hash_regions(f->hp, l0.P, cu_count(f->device)); // pass-A workgroups: one or two per CU
@@ -2201,7 +2207,7 @@ int split_contains(btlbf_filter* f, const SeqArgs& a, int direct_op, hipStream_t
 		PartGrid g;
 		// (up to a quarter of the reads cold: beyond that the lanes pass A spends on zero-staged reads cost more than
 		// gathering the warm reads costs -- at one read in two 76 instead of 43 ms of pass A per 10^8 reads)
-		if (4 * n_cold <= n_reads && plan_level0(f, pl0, (double)a.len * f->hp.h) && part_read_grid(f->hp, pl0.lv[0].P, a.layout, &g)) {
+		if (4 * n_cold <= n_reads && plan_level0(f, pl0, call_probes(f, a.len)) && part_read_grid(f->hp, pl0.lv[0].P, a.layout, &g)) {
 			const uint64_t szm[5] = {up(cold_len + 16), up(bitmap_bytes(cold_len) + 16), wv ? up(bitmap_bytes(cold_len) + 16) : 0,
 			                         up(n_cold * 4 + 16), a.hit_bits ? 0 : up(bitmap_bytes(a.len) + 16)};
 			uint64_t need = 0;

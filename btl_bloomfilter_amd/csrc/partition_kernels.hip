@@ -590,6 +590,8 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bi
 	PartFront fr;
 	PartGrid g;
 	const bool grid = part_read_grid(a.hp, out.P, a.layout, &g);
+	if (a.read_mask && !grid) // the mask is one bit per read of the grid: the caller planned with other bins than it runs with
+		return hipErrorInvalidValue;
 	// ragged layout: room for the start bitmap of the overlapped schedule behind the tile image, if the LDS has it
 	// without giving up the positional table (part_hash_inst.hip; the plain kernels leave it unused)
 	a.sb_words = 0;
