@@ -72,7 +72,12 @@ __global__ __launch_bounds__(SMALL ? kPartThreadsS : kPartThreads, SMALL ? 4 : 1
 	// a power-of-two filter taken whole: bin and entry are bit fields of the hash itself (no 64-bit `& mask` first)
 	const uint32_t bin_mask = (uint32_t)(a.mod.mask >> bin_shift);
 	const uint32_t ent_mask_p2 = ent_mask & (uint32_t)a.mod.mask; // a filter smaller than one bin
-	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, part_bin_base(sd, b, bin_shift) + v); };
+	// (a power-of-two filter taken whole never has bins of whole segments, and must not read sd.bin_* here: with
+	// part_bin_base for every variant the benchmark's query kernel spilled 16 bytes per lane and ran 44 instead of
+	// 41 ms, the ragged insert 55.6 instead of 46.5 -- tools/kres.py after every change to this file)
+	auto ovf = [&](uint32_t b, uint32_t v) {
+		part_direct<QUERY>(words, sd, POW2 && !WINDOW ? ((uint64_t)b << bin_shift) | v : part_bin_base(sd, b, bin_shift) + v);
+	};
 	const uint64_t out_bytes = ((a.len + 63) / 64) * 8;
 	uint32_t my_valid = 0;
 
@@ -328,7 +333,12 @@ __global__ __launch_bounds__(kPartThreads, 1) void part_hash_ov_kernel(const Seq
 	// a power-of-two filter taken whole: bin and entry are bit fields of the hash itself (no 64-bit `& mask` first)
 	const uint32_t bin_mask = (uint32_t)(a.mod.mask >> bin_shift);
 	const uint32_t ent_mask_p2 = ent_mask & (uint32_t)a.mod.mask; // a filter smaller than one bin
-	auto ovf = [&](uint32_t b, uint32_t v) { part_direct<QUERY>(words, sd, part_bin_base(sd, b, bin_shift) + v); };
+	// (a power-of-two filter taken whole never has bins of whole segments, and must not read sd.bin_* here: with
+	// part_bin_base for every variant the benchmark's query kernel spilled 16 bytes per lane and ran 44 instead of
+	// 41 ms, the ragged insert 55.6 instead of 46.5 -- tools/kres.py after every change to this file)
+	auto ovf = [&](uint32_t b, uint32_t v) {
+		part_direct<QUERY>(words, sd, POW2 && !WINDOW ? ((uint64_t)b << bin_shift) | v : part_bin_base(sd, b, bin_shift) + v);
+	};
 	uint32_t my_valid = 0;
 
 	const uint64_t t_begin = a.first_tile + (uint64_t)blockIdx.x * a.tiles_per_block;

@@ -35,5 +35,9 @@ sq)
 sq3x) # one shape alone
 	QB_BITS='3*2**37' sq_pass passA_3x2p37 39 20000000 partitioned partitioned hitonly
 	;;
+sqbins) # 512 against 256 level-0 bins on the same filter (2^37 bits, plain ntHash)
+	BTLBF_SPLIT_BITS=9 QB_BITS='2**37' sq_pass passA_2p37_512bins 39 20000000 partitioned partitioned hitonly
+	BTLBF_SPLIT_BITS=10 QB_BITS='2**37' sq_pass passA_2p37_256bins 39 20000000 partitioned partitioned hitonly
+	;;
 esac
 echo session $1 done
