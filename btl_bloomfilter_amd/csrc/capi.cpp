@@ -504,6 +504,19 @@ int build_spaced(HashParams& hp, const char* const* seeds, unsigned n_seeds, uns
 			dcu.clear();
 			hp.n_dcu_all = 0;
 		}
+		// two-base rows for the pairs (seq_core.hpp): the hash stage takes two pairs per trip, so an even number of
+		// them -- a pair of fillers with an empty mask if need be; at most 16 rows (4 KB of LDS)
+		hp.want_pair_rows = hp.n_pair_rows = 0;
+		if (!dcu.empty()) {
+			size_t pairs = (dcu.size() - hp.n_dcu_all) / 2;
+			if (pairs % 2 && dcu.size() + 2 <= kMaxDcu) {
+				dcu.push_back(k);
+				dcu.push_back(k);
+				++pairs;
+			}
+			if (pairs && pairs % 2 == 0 && pairs <= 16)
+				hp.want_pair_rows = (uint32_t)pairs;
+		}
 		hp.n_dcu = (uint32_t)dcu.size();
 	}
 	const size_t dc_bytes = (dc.size() * 2 + 15) / 16 * 16;

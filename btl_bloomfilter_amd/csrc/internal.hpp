@@ -77,6 +77,11 @@ struct HashParams {
 	// not available (more than kMaxDcu = 64 offsets: the kernels keep the list in one register of a wave), the per-seed lists above are walked instead.
 	const uint32_t* dcu;
 	uint32_t n_dcu, n_dcu_all;
+	// The entries behind the first n_dcu_all come in PAIRS with one mask.  want_pair_rows (set with the list; 0 = none):
+	// the pairs, an even number of them, can be served by two-base table rows of 256 bytes each -- row[c1][c2] = the sum
+	// of the pair's two terms for the bases A C G T -- if a launcher finds the LDS for them; n_pair_rows is the launcher's
+	// answer (the kernels' view: rows behind the union list in LDS, or 0 = one table read per offset).
+	uint32_t want_pair_rows, n_pair_rows;
 };
 static constexpr uint32_t kMaxDcu = 64;
 

@@ -603,8 +603,21 @@ hipError_t launch_part_hash(const SeqArgs& a_in, const PartOut& out, uint32_t bi
 		    fr.use_pos_tab == plain.use_pos_tab)
 			a.sb_words = sb_bytes / 4;
 	}
-	if (!part_front(a.hp, out.P, fr, grid ? g.cap : a.sb_words ? seq_tile_cap(kPartTile, a.hp.k) + a.sb_words * 4 : 0))
+	const uint32_t tile_lds = grid ? g.cap : a.sb_words ? seq_tile_cap(kPartTile, a.hp.k) + a.sb_words * 4 : 0;
+	a.hp.n_pair_rows = 0; // (everything above was planned without them)
+	if (!part_front(a.hp, out.P, fr, tile_lds))
 		return hipErrorInvalidValue;
+	// spaced seeds: two-base rows for the union list's pairs (seq_core.hpp) where the LDS still has the room -- with 256
+	// level-0 bins it has (3 KB fewer per-bin words than with 512), and nothing else gives way for them
+	if (a.hp.want_pair_rows && !fr.small) {
+		HashParams with = a.hp;
+		with.n_pair_rows = a.hp.want_pair_rows;
+		PartFront fr2;
+		if (part_front(with, out.P, fr2, tile_lds) && !fr2.small && fr2.use_pos_tab == fr.use_pos_tab) {
+			a.hp.n_pair_rows = with.n_pair_rows;
+			fr = fr2;
+		}
+	}
 	a.rg_reads = g.reads;
 	a.rg_gpr = g.gpr;
 	a.rg_lpad = g.lpad;

@@ -75,9 +75,14 @@ __host__ __device__ inline uint32_t seq_dc_list_bytes(const HashParams& hp)
 	return hp.n_seeds ? ((hp.dc_off[hp.n_seeds] * 2 + 15) / 16) * 16 : 0;
 }
 // ... followed by the union list of distinct don't-care offsets (HashParams::dcu), 4 bytes each
+// ... and, where a launcher found room (HashParams::n_pair_rows), the two-base rows of the list's pairs, 256 bytes each
+__host__ __device__ inline uint32_t seq_union_list_bytes(const HashParams& hp)
+{
+	return hp.n_seeds ? ((hp.n_dcu * 4 + 15) / 16) * 16 : 0;
+}
 __host__ __device__ inline uint32_t seq_spaced_bytes(const HashParams& hp)
 {
-	return seq_pos_tab_bytes(hp) + seq_dc_list_bytes(hp) + (hp.n_seeds ? ((hp.n_dcu * 4 + 15) / 16) * 16 : 0);
+	return seq_pos_tab_bytes(hp) + seq_dc_list_bytes(hp) + seq_union_list_bytes(hp) + (hp.n_seeds ? hp.n_pair_rows * 256 : 0);
 }
 
 // one-time table setup; callers __syncthreads() before first use (seq_stage_tile does)
@@ -133,6 +138,23 @@ __device__ __forceinline__ void seq_setup_tables(SeqShared& sh, const HashParams
 		uint32_t* du = reinterpret_cast<uint32_t*>(spaced_lds + seq_pos_tab_bytes(hp) + seq_dc_list_bytes(hp));
 		for (uint32_t i = tid; i < hp.n_dcu; i += NT)
 			du[i] = hp.dcu[i];
+		// two-base rows of the list's pairs: row p, entry (c1, c2) = term(offset 1, c1) ^ term(offset 2, c2) for A C G T;
+		// the filler "offset" k contributes nothing
+		U64x2* pr = reinterpret_cast<U64x2*>(spaced_lds + seq_pos_tab_bytes(hp) + seq_dc_list_bytes(hp) + seq_union_list_bytes(hp));
+		for (uint32_t i = tid; i < hp.n_pair_rows * 16; i += NT) {
+			const uint32_t p = i / 16, c1 = (i / 4) % 4, c2 = i % 4;
+			const uint32_t o1 = hp.dcu[hp.n_dcu_all + 2 * p] & 0xffffu, o2 = hp.dcu[hp.n_dcu_all + 2 * p + 1] & 0xffffu;
+			U64x2 t{0, 0};
+			if (o1 < hp.k) {
+				t.x ^= srol_n(hp.init_tab[c1][0], hp.k - 1 - o1);
+				t.y ^= srol_n(hp.out_tab[c1][1], o1);
+			}
+			if (o2 < hp.k) {
+				t.x ^= srol_n(hp.init_tab[c2][0], hp.k - 1 - o2);
+				t.y ^= srol_n(hp.out_tab[c2][1], o2);
+			}
+			pr[i] = t;
+		}
 	}
 }
 
@@ -704,7 +726,63 @@ __device__ __forceinline__ void seq_lane_range(const uint8_t* tile, const SeqSha
 				// and the sum goes into the seeds of the mask -- one set of scalar branches per pair, and for a mask of n
 				// seeds 1 + n XORs of a term instead of 2n
 				static_assert(CHK == 2, "offsets are paired by mask");
-				for (u = n_all; u < n_dcu; u += 2) {
+				// With two-base rows in LDS (hp.n_pair_rows: a launcher found the room) a pair costs ONE table read per window
+				// and no XOR of its two terms; two pairs per trip.  The rows hold A C G T only: a group that meets one of the
+				// raw-byte codes 4..7 at a listed offset is done again the one-offset way below (`redo`, by its whole wave).
+				bool redo = hp.n_pair_rows == 0;
+				if (!redo) {
+					const uint8_t* prow = spaced_lds + seq_pos_tab_bytes(hp) + seq_dc_list_bytes(hp) + seq_union_list_bytes(hp);
+					uint32_t raw = 0;
+					for (u = n_all; u < n_dcu; u += 4) {
+						uint32_t e[4], b[4][GRP];
+#pragma unroll
+						for (int c = 0; c < 4; ++c) {
+							e[c] = entry(u + c);
+							const uint32_t off = e[c] & 0xffffu;
+#pragma unroll
+							for (int q = 0; q < GRP; ++q) {
+								b[c][q] = bp[g0 + off + q];
+								// (a filler reads the base behind the window: a raw byte there sends the group the long way
+								// round for nothing, which is cheaper than a test per entry)
+								raw |= b[c][q];
+							}
+						}
+						U64x2 tt[2][GRP];
+#pragma unroll
+						for (int p = 0; p < 2; ++p) {
+							const uint32_t row = ((u - n_all) / 2 + p) * 256;
+#pragma unroll
+							for (int q = 0; q < GRP; ++q)
+								tt[p][q] = tab16(prow, row + (((b[2 * p][q] << 2) & 0xc0u) | (b[2 * p + 1][q] & 0x30u)));
+						}
+#pragma unroll
+						for (int p = 0; p < 2; ++p) {
+							const uint32_t m = e[2 * p] >> 16;
+#pragma unroll
+							for (int j = 0; j < HS; ++j) {
+								if ((m >> j) & 1u) {
+#pragma unroll
+									for (int q = 0; q < GRP; ++q) {
+										af[q][j] ^= tt[p][q].x;
+										ar[q][j] ^= tt[p][q].y;
+									}
+								}
+							}
+						}
+					}
+					redo = __any((raw & 0x40u) != 0) != 0; // (the whole wave: the loops below stay uniform)
+					if (redo) {
+#pragma unroll
+						for (int q = 0; q < GRP; ++q) {
+#pragma unroll
+							for (int j = 0; j < HS; ++j) {
+								af[q][j] = bf[q];
+								ar[q][j] = br[q];
+							}
+						}
+					}
+				}
+				for (u = n_all; redo && u < n_dcu; u += 2) {
 					uint32_t e[CHK], span[CHK];
 					U64x2 tt[CHK][GRP];
 					e[0] = entry(u);

@@ -1189,6 +1189,46 @@ def test_partitioned_ragged_layout_start_bitmap(bf, shape):
     assert abs(res["direct"][2][0] - want_clean) <= 2 * k  # (the N and the foreign stretch's seams)
 
 
+@pytest.mark.parametrize("p_raw", [0.0, 0.0005, 0.2])
+@pytest.mark.parametrize("bits", [1 << 26, 1 << 27, 3 << 25])
+def test_partitioned_spaced_seeds_two_base_rows_and_raw_bytes(bf, oracle, bits, p_raw):
+    """Config 5's seeds on filters of at most 256 level-0 bins, where pass A has the LDS for the two-base rows of the
+    union list's pairs (seq_core.hpp: one table read per pair and window; A C G T only).  Reads with the raw bytes the
+    reference's seed table also takes (1 3 4 5 7) -- rare, so that most groups of windows take the rows and a few are
+    done again the one-offset way, and dense -- and lower-case / U / N: against the direct kernels (per-seed walk of the
+    single-base table) and, for the first reads, against the oracle's stHashIterator walk."""
+    import torch
+
+    seeds = ["1110111011101110111011101110111", "1101101101101101011011011011011",
+             "1111001111001111111001111001111", "1011101011101011101011101011101"]
+    k, L, n = 31, 150, 40000
+    rng = np.random.RandomState(int(bits % 977) + int(p_raw * 1e4))
+    s = rng.choice(list(b"ACGTacgtU"), n * L).astype(np.uint8)
+    raw = rng.rand(n * L) < p_raw
+    s[raw] = rng.choice(list(b"\x01\x03\x04\x05\x07"), int(raw.sum()))
+    s[rng.rand(n * L) < 0.0005] = ord("N")
+    reads = torch.from_numpy(s).cuda()
+    a, b = bf.BloomFilter(bits, 4, k), bf.BloomFilter(bits, 4, k)
+    for f, mode in ((a, "direct"), (b, "partitioned")):
+        f.setSpacedSeeds(seeds, 1)
+        f.setInsertMode(mode)
+        f.setQueryMode(mode)
+        f.insertSeqs(reads, read_len=L)
+    torch.cuda.synchronize()
+    assert a.getPop() == b.getPop() > 0
+    assert (a.download() == b.download()).all()
+    q = torch.cat([reads[: 5000 * L], bf.synth_reads_device(12, 0, 300, L)])
+    ha, va, ca = a.containsSeqs(q, read_len=L, want_counts=True)
+    hb, vb, cb = b.containsSeqs(q, read_len=L, want_counts=True)
+    assert ca.tolist() == cb.tolist() and torch.equal(ha, hb) and torch.equal(va, vb)
+    body = b.download()
+    host = s.tobytes()
+    for r in range(12):
+        pos, hv, _ = oracle.sthash_seq(host[r * L: (r + 1) * L], seeds, 1, k)
+        pp = (hv % np.uint64(bits)).ravel().astype(np.int64)
+        assert ((body[pp >> 3] >> (pp & 7)) & 1).all(), "read %d" % r
+
+
 @pytest.mark.parametrize("n_seeds,h2,k,L", [(6, 1, 31, 150), (8, 1, 25, 100), (4, 2, 47, 151), (2, 1, 96, 250), (3, 1, 8, 60)])
 def test_partitioned_spaced_seed_union_list_shapes(bf, oracle, n_seeds, h2, k, L):
     """Random spaced seeds through pass A's union list of don't-care offsets (seq_core.hpp): more than four hashes per

@@ -39,5 +39,8 @@ sqbins) # 512 against 256 level-0 bins on the same filter (2^37 bits, plain ntHa
 	BTLBF_SPLIT_BITS=9 QB_BITS='2**37' sq_pass passA_2p37_512bins 39 20000000 partitioned partitioned hitonly
 	BTLBF_SPLIT_BITS=10 QB_BITS='2**37' sq_pass passA_2p37_256bins 39 20000000 partitioned partitioned hitonly
 	;;
+sqspaced) # C5's kernel alone
+	QB_SPACED=1 sq_pass passA_spaced 37 20000000 partitioned partitioned hitonly
+	;;
 esac
 echo session $1 done
