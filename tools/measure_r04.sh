@@ -2,6 +2,7 @@
 # round-4 measurement session (GPU box, repository root), in parts so that each fits one gpurun call:
 #   tools/measure_r04.sh bench   -> contract bench (with side_configs), rocprofv3 kernel stats, PMC traffic
 #   tools/measure_r04.sh sq      -> SQ counters of pass A: C2, spaced seeds (C5), ragged layout, 3*2^37 bits
+#   tools/measure_r04.sh sq3x | sqspaced | sqbins -> one of those shapes alone / 512 against 256 level-0 bins at 2^37 bits
 set -e
 ROOT=$(pwd); O=$ROOT/gpurun_out/r04; mkdir -p $O
 export TMPDIR=/tmp
