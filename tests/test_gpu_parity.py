@@ -93,7 +93,7 @@ def test_nthash_random_vs_oracle(bf, oracle, k, h):
 @pytest.mark.parametrize("k", [2, 3, 5, 8, 30, 31, 33, 64, 127, 128])
 def test_nthash_start_up_pair_table_and_raw_byte_codes(bf, oracle, k):
     # a lane's first window comes from a two-base table that holds A C G T only (seq_core.hpp); windows with one of
-    # the other bytes the reference's seed table gives a value (1 3 4 5 7, U) take the Horner form: both, densely
+    # the other bytes the reference's seed table gives a value (the raw bytes 1 3 4 5 7; U and u share T's code) take the Horner form: both, densely
     # mixed, at even and odd k, against the oracle (reference: nthash.hpp:129-147 NTMC64 initial values)
     rng = np.random.RandomState(900 + k)
     for alpha, p_raw in ((b"\x01\x03\x04\x05\x07Uu", 0.01), (b"\x01\x03\x04\x05\x07Uu", 0.3), (b"\x00\x02\x06Nn", 0.05)):
