@@ -1785,10 +1785,14 @@ bool want_partitioned(const btlbf_filter* f, uint64_t len, int counting_op = -1)
 }
 
 // the segment size and the level-0 bins (pass A's output) of this filter's local array; false = no partitioned path
-// probes a call over `len` bases sends to this filter's local array (a shard keeps its window's share)
+// probes a call over `len` bases sends to this filter's local array (a shard keeps its window's share) -- or, with a
+// scratch budget imposed by the caller, what one batch of that budget holds (about 5.5 bytes of scratch per probe): the
+// figure plan_level0's batch-size rule goes by.  (Deterministic on purpose: the split query plans twice and both plans
+// must agree; the free-memory budget would not be the same figure twice.)
 double call_probes(const btlbf_filter* f, uint64_t len)
 {
-	return (double)len * f->hp.h * ((double)f->mod.shard_len / (double)f->mod.size);
+	const double all = (double)len * f->hp.h * ((double)f->mod.shard_len / (double)f->mod.size);
+	return f->part_budget ? std::min(all, (double)f->part_budget / 5.5) : all;
 }
 
 // `call_probes`: probes of the whole call (0 = unknown), for the one choice that depends on the batch size
