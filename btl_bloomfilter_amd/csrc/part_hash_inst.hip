@@ -1,6 +1,7 @@
 // csrc/part_hash_inst.hip -- pass A of the partitioned pipeline (fused ntHash + radix partition),
 // compiled once per hash count: -DBTLBF_PART_H=n defines launch_part_hash_h<n>.  One translation
 // unit per n keeps the build parallel (each holds 8 variants of a large kernel).
+#define BTLBF_NT_FLUSH 1 // chunk flushes as streaming stores in this translation unit (partition_core.hpp part_round_p2)
 #include "partition_core.hpp"
 #include <cstdlib>
 #include <cstring>

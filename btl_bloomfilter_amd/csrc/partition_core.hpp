@@ -375,7 +375,15 @@ __device__ __forceinline__ void part_round_p2(const PartLds& l, const PartOut& o
 		const uint32_t it = l.flist[slice + j], wc = l.fwc[slice + j];
 		const uint4 v = *reinterpret_cast<const uint4*>(&l.stage[it * kChunk + l4 * 4]);
 		if (wc != 0xffffffffu) {
+#ifdef BTLBF_NT_FLUSH // pass A (part_hash_inst.hip defines it): streaming stores for the chunks, so that they do not
+			// push the late image and the reads out of the L2 -- pass A 39.35 -> 39.0 ms, query 41.3 -> 40.8; pass B, whose
+			// workgroups have nothing else to keep there, is 1 % slower with them and keeps plain stores
+			typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+			v4u_t vv = {v.x, v.y, v.z, v.w};
+			__builtin_nontemporal_store(vv, reinterpret_cast<v4u_t*>(&o.ent[(uint64_t)wc * kChunk + l4 * 4]));
+#else
 			*reinterpret_cast<uint4*>(&o.ent[(uint64_t)wc * kChunk + l4 * 4]) = v;
+#endif
 		} else {
 			const uint32_t fb = it >> cshift;
 			ovf(fb, v.x);
